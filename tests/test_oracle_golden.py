@@ -1,0 +1,123 @@
+"""Pins the CPU oracle (oracle/stcat_oracle.py) against golden vectors produced by
+the imported reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stcat_oracle as O
+from stcat_amd import synth
+
+from tests.golden.make_golden import sub  # same deterministic sub-sampling
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _close(a, b, tol, what):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(1.0, np.abs(b).max() if b.size else 1.0)
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3g}) > {tol}"
+
+
+@pytest.fixture(scope="module")
+def c1(golden_dir):
+    g = _load(golden_dir, "C1.npz")
+    T, res, L = [int(v) for v in g["meta/config"]]
+    sd = synth.synth_state_dict()
+    for v in sd.values():
+        v.requires_grad_(True)
+    frames = synth.synth_frames(T, res)
+    mask = torch.zeros(T, res, res, dtype=torch.bool)
+    text = synth.synth_text(L)
+    out = O.stcat_forward(sd, frames, mask, text, return_stages=True)
+    return g, sd, out, (T, res, L)
+
+
+def test_state_dict_keys_match_reference(c1):
+    g, sd, _, _ = c1
+    ref_keys = set(str(k) for k in g["meta/state_dict_keys"])
+    assert set(sd.keys()) == ref_keys
+
+
+def test_forward_stages(c1):
+    g, _, out, _ = c1
+    st = out["_stages"]
+    for k in ("layer1", "layer2", "layer3", "layer4", "vis_pos", "input_proj", "encoded_memory"):
+        _close(sub(st[k]), g[f"stage/{k}"], 2e-5, k)
+    for k in ("frames_cls", "videos_cls", "pos_query", "hs", "ref", "time_hs", "weights"):
+        _close(st[k].detach().numpy(), g[f"stage/{k}"], 2e-5, k)
+
+
+def test_forward_outputs(c1):
+    g, _, out, _ = c1
+    for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights"):
+        _close(out[k].detach().numpy(), g[f"out/{k}"], 2e-5, k)
+        for i, aux in enumerate(out["aux_outputs"]):
+            _close(aux[k].detach().numpy(), g[f"out/aux{i}/{k}"], 2e-5, f"aux{i}/{k}")
+
+
+def test_post_process(c1):
+    g, _, out, (T, res, L) = c1
+    sizes = torch.tensor([[float(res), float(res)]]).repeat(T, 1)
+    boxes, sted, _ = O.post_process(out["pred_sted"].detach(), out["pred_boxes"].detach(), sizes,
+                                    list(range(100, 100 + T)), T)
+    _close(boxes.numpy(), g["post/boxes"], 2e-5, "post boxes")
+    assert sted == [int(v) for v in g["post/sted"][0]]  # bit-exact span
+
+
+def test_loss_and_grads(c1):
+    g, sd, out, (T, res, L) = c1
+    act, boxes = synth.synth_targets(T)
+    losses = O.criterion(out, act, boxes)
+    keys = [str(k) for k in g["loss/keys"]]
+    assert sorted(losses.keys()) == keys
+    vals = np.asarray([losses[k].item() for k in keys])
+    _close(vals, g["loss/values"], 2e-5, "loss values")
+    wd = O.weight_dict()
+    _close(np.asarray([wd[k] for k in keys]), g["loss/weights"], 0, "weight dict")
+    total = O.total_loss(losses, wd)
+    _close(total.item(), g["loss/total"], 2e-5, "total")
+    total.backward()
+    unused = set(str(k) for k in g["grad/unused"])
+    names = [str(n) for n in g["grad/names"]]
+    norms = []
+    for n in names:
+        gr = sd[synth.canonical_name(n)].grad
+        assert gr is not None, n
+        norms.append(gr.norm().item())
+    _close(np.asarray(norms), g["grad/norms"], 1e-4, "grad norms")
+    for n in unused:
+        assert sd[n].grad is None or float(sd[n].grad.abs().max()) == 0.0, n
+    for k in g.files:
+        if k.startswith("grad/full/"):
+            n = k[len("grad/full/"):]
+            _close(sub(sd[synth.canonical_name(n)].grad), g[k], 1e-4, k)
+
+
+def test_op_vectors(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    _close(O.gen_sineembed(torch.from_numpy(g["sine/anchors"])).numpy(), g["sine/embed"], 1e-6, "sine")
+    _close(O.inverse_sigmoid(torch.from_numpy(g["invsig/x"])).numpy(), g["invsig/y"], 1e-6, "invsig")
+    _close(O.pos_sine_2d(torch.from_numpy(g["pos2d/mask"])).numpy(), g["pos2d/pos"], 1e-6, "pos2d")
+    _close(synth.time_sine_table(301)[:10], g["seqsine/te"], 1e-6, "seq sine")
+    sd = {"x.out_proj.weight": torch.from_numpy(synth.synth_value("op/dab/out_proj.weight", (256, 256))),
+          "x.out_proj.bias": torch.from_numpy(synth.synth_value("op/dab/out_proj.bias", (256,)))}
+    q = torch.from_numpy(synth.hash_normal("op/dab/q", 3 * 512).reshape(1, 3, 512))
+    k = torch.from_numpy(synth.hash_normal("op/dab/k", 11 * 3 * 512).reshape(11, 3, 512))
+    v = torch.from_numpy(synth.hash_normal("op/dab/v", 11 * 3 * 256).reshape(11, 3, 256))
+    o = O.dab_mha(sd, "x.", q, k, v, torch.from_numpy(g["dab/kpm"]))
+    _close(o.numpy(), g["dab/out"], 1e-5, "dab mha")
+    sted = torch.from_numpy(g["post/in_sted"])
+    boxes = torch.from_numpy(g["post/in_boxes"])
+    T = sted.shape[1]
+    sizes = torch.tensor([[240.0, 320.0]]).repeat(T, 1)
+    for dur in (12, 9, 6):
+        pb, st, _ = O.post_process(sted, boxes, sizes, list(range(50, 50 + T)), dur)
+        assert st == [int(v) for v in g[f"post/dur{dur}/sted"][0]], dur
+    _close(pb.numpy(), g["post/boxes"], 1e-6, "post boxes")
