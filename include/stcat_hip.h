@@ -1,0 +1,133 @@
+/* libstcat_hip — C ABI of the MI355X-native STCAT hot path.
+ *
+ * The reference (jy0205/STCAT) is pure PyTorch: it has no FFI of its own, every
+ * kernel it runs is reached through torch.nn modules.  Each entry point below
+ * therefore replaces a torch call site of the hot path and cites it
+ * (file:line relative to the reference checkout).  INTEGRATION.md shows the
+ * ctypes binding and the factory seam (models/pipeline.py:6-8) a maintainer
+ * plugs them into.
+ *
+ * Conventions
+ *   - all tensors are fp32 device pointers (HIP), dense unless a leading
+ *     dimension is given; activations are NHWC / token-major [rows][features];
+ *     conv weights are OHWI (== a torch [O,I,H,W] tensor in channels_last).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - return 0 on success; <0 = invalid argument (see stcat_last_error());
+ *     >0 = hipError_t of the failed launch.  Nothing is allocated or freed,
+ *     no host synchronisation happens inside any call (graph-capture safe).
+ */
+#ifndef STCAT_HIP_H_
+#define STCAT_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int stcat_version(void);
+const char* stcat_last_error(void);
+/* tuning/test hook: force the implicit-GEMM block tile (128x128, 128x64, 64x64; 0,0 = heuristic) */
+int stcat_debug_force_tile(int bm, int bn);
+
+/* ---- backbone: torchvision ResNet-101 + FrozenBatchNorm2d (models/vision_model/backbone.py:16-66,
+ *      93-121; torch conv2d/max_pool2d underneath) ------------------------------------------------ */
+
+/* scale = w*rsqrt(rv+eps), bias = b - rm*scale  (backbone.py:56-66) */
+int stcat_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                         float* bias, int C, float eps, void* stream);
+/* stem 7x7/2 pad 3 conv on the NCHW frame tensor [n,3,H,W] with OIHW weight [64,3,7,7],
+ * + FrozenBN + ReLU -> NHWC [n,H/2,W/2,64]  (resnet conv1/bn1/relu) */
+int stcat_stem_fwd(const float* frames, const float* w, const float* scale, const float* bias, float* y, int n,
+                   int H, int W, void* stream);
+/* 3x3/2 pad 1 max-pool, NHWC (resnet maxpool) */
+int stcat_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream);
+/* y = relu?(scale*conv(x,w) + bias + res), x NHWC [n,H,W,Cin], w OHWI [Cout,KH,KW,Cin]
+ * (Bottleneck conv+bn(+add)+relu; any of scale/bias/res may be NULL) */
+int stcat_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* res,
+                   float* y, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   int relu, void* stream);
+/* dx = conv_transpose(g, w) (+ add): g NHWC [n,OH,OW,Cout] -> dx NHWC [n,H,W,Cin]  (autograd of conv2d) */
+int stcat_conv_dgrad(const float* g, const float* w, const float* add, float* dx, int n, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* dw (OHWI, caller-zeroed) += sum over pixels g (x) gathered x  (autograd of conv2d w.r.t. weight) */
+int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream);
+/* backward of y = relu?(scale*z + bias (+res)): dz = dy*[y>0]; G = dz*scale[c] (may be NULL); dres = dz (may be NULL) */
+int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G, float* dres, long n, int C,
+                  int relu, void* stream);
+
+/* ---- position embeddings ------------------------------------------------------------------------ */
+/* PositionEmbeddingSine(128, normalize=True) (vision_model/position_encoding.py:70-94):
+ * mask [n,h,w] bytes (1 = pad) -> pos [n,h*w,256]; dimt = 128 host-computed divisors */
+int stcat_pos_sine_2d(const unsigned char* mask, const float* dimt, float* pos, int n, int h, int w, void* stream);
+/* gen_sineembed_for_position (models/net_utils.py:29-56): anchors [M,4] -> [M,512], and its gradient */
+int stcat_sine_embed_fwd(const float* anchor, const float* dimt, float* out, int M, void* stream);
+int stcat_sine_embed_bwd(const float* anchor, const float* dimt, const float* dout, float* danchor, int M,
+                         void* stream);
+
+/* ---- Linear / LayerNorm / glue (torch.nn.Linear, LayerNorm call sites in modal_encoder.py:207-242,
+ *      query_decoder.py:250-438, 553-660, net_utils.py:7-26, pipeline.py:41) -------------------- */
+/* y[m, :N] = relu?(x[m,:K] . w[N,K]^T + bias + res[m]); output row m is written at
+ * (m / c_group)*c_group_stride + (m % c_group)*ldy  (c_group <= 0: plain m*ldy).  N % 64 == 0, K % 16 == 0. */
+int stcat_linear_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                     int K, int ldx, int ldy, int ldr, int relu, int c_group, long c_group_stride, void* stream);
+/* dx[M,K] = g[M,N] . w[N,K] (+ add[M,K]);  K % 64 == 0, N % 16 == 0 */
+int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
+                       int lddx, void* stream);
+/* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0 */
+int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, int K, int ldg, int ldx,
+                       void* stream);
+/* narrow heads, N <= 16, K % 4 == 0 */
+int stcat_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                           void* stream);
+int stcat_small_linear_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int M,
+                           int N, int K, void* stream);
+/* out[N] (caller-zeroed) += sum_m a[m,n] * (b ? b[m,n] : 1) */
+int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);
+/* LayerNorm over 256 features of (x + res); saves mean / rstd per row */
+int stcat_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int M, int D, float eps, void* stream);
+int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
+                        const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D, void* stream);
+/* element-wise glue; op codes STCAT_EW_* below; b indexed modulo bmod */
+int stcat_ew(int op, const float* a, const float* b, const float* c, float* out, long n, long bmod, float alpha,
+             float beta, void* stream);
+enum {
+  STCAT_EW_ADD = 0, STCAT_EW_MUL = 1, STCAT_EW_SIGMOID = 2, STCAT_EW_TANH = 3, STCAT_EW_RELU = 4,
+  STCAT_EW_INVSIG = 5, STCAT_EW_SIGMOID_BWD = 6, STCAT_EW_TANH_BWD = 7, STCAT_EW_INVSIG_BWD = 8,
+  STCAT_EW_ADD3 = 9, STCAT_EW_AXPBY = 10, STCAT_EW_COPY = 11
+};
+
+/* ---- attention ---------------------------------------------------------------------------------- */
+/* torch.nn.MultiheadAttention core after the in-projection (modal_encoder.py:236; query_decoder.py:341,
+ * 604-610): per (batch, head) softmax(scale * q k^T + key_padding) v with head dim 32, S <= 256.
+ * q/k/v/o are [B,S,ld*] with head h at column h*32.  pt receives the probabilities as
+ * [B,H,Sp,Sp] (Sp = 32*ceil(S/32), key-major) for the backward pass / head-mean weights. */
+int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o,
+                       float* pt, int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                       void* stream);
+/* out = forward output; dw (may be NULL) = gradient of the head-averaged weights [B,S,S] and then
+ * corr = [B,H,S] scratch; dst = [B,H,Sp,Sp] scratch; dq/dk are [B,S,ldg], dv is [B,S,ldgv] */
+int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                       const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
+                       int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
+                       void* stream);
+/* head-averaged weights [B,S,S] (need_weights=True; consumed at pipeline.py:84-85) */
+int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, void* stream);
+/* time-aligned cross-attention with ONE query per frame (query_decoder.py:386-417 via
+ * grounding_model/attention.py:184-393; query_decoder.py:618-639): per (frame, head)
+ * softmax(scale*(q1.k1 + q2.k2)) v, each part 32 wide; q2/k2 may be NULL.  P [B,H,S] is kept for backward. */
+int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
+                      const unsigned char* kpm, float* out, float* P, int B, int H, int S, int ldq, int ldk,
+                      int ldv, float scale, void* stream);
+int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
+                      const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
+                      int B, int H, int S, int ldq, int ldk, int ldv, float scale, void* stream);
+
+/* ---- live 2D temporal map (models/post_processor.py:30-53) -------------------------------------- */
+/* sted [b,T,2], durations [b] (device int32) -> out [b,2] device int32 (start_idx, end_idx), T <= 1024 */
+int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out, int b, int T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STCAT_HIP_H_ */

@@ -1,0 +1,121 @@
+"""ctypes binding of libstcat_hip.so (C ABI declared in include/stcat_hip.h).
+
+The product path has exactly one backend: the HIP library built for gfx950.
+If it is missing, loading fails loudly — there is no CPU or PyTorch fallback.
+(`_use_library_for_testing` lets the CPU test-suite inject the host SIMT
+emulator build of the *same* kernel sources, tests/emu/; nothing in the
+package calls it.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstcat_hip.so")
+
+# name -> argument kinds: p = device pointer, i = int, l = long, f = float, s = stream (void*)
+SIGNATURES: Dict[str, str] = {
+    "stcat_frozen_bn_fold": "ppppppifs",
+    "stcat_stem_fwd": "pppppiiis",
+    "stcat_maxpool3x3s2": "ppiiiis",
+    "stcat_conv_fwd": "ppppppiiiiiiiiiis",
+    "stcat_conv_dgrad": "ppppiiiiiiiiis",
+    "stcat_conv_wgrad": "pppiiiiiiiiis",
+    "stcat_act_bwd": "ppppplii" + "s",
+    "stcat_pos_sine_2d": "pppiiis",
+    "stcat_sine_embed_fwd": "pppis",
+    "stcat_sine_embed_bwd": "ppppis",
+    "stcat_linear_fwd": "pppppiiiiiiiils",
+    "stcat_linear_dgrad": "ppppiiiiis",
+    "stcat_linear_wgrad": "pppiiiiis",
+    "stcat_small_linear_fwd": "ppppiiis",
+    "stcat_small_linear_bwd": "ppppppiiis",
+    "stcat_colsum": "pppiis",
+    "stcat_layernorm_fwd": "pppppppiifs",
+    "stcat_layernorm_bwd": "pppppppppiis",
+    "stcat_ew": "ipppp" + "llffs",
+    "stcat_mha_self_fwd": "ppppppiiiiiiifs",
+    "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiifs",
+    "stcat_attn_weights_mean": "ppiiis",
+    "stcat_attn_q1_fwd": "pppppppp" + "iiiiiifs",
+    "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiifs",
+    "stcat_temporal_map_argmax": "pppiis",
+    "stcat_debug_force_tile": "ii",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
+
+EW_ADD, EW_MUL, EW_SIGMOID, EW_TANH, EW_RELU, EW_INVSIG = 0, 1, 2, 3, 4, 5
+EW_SIGMOID_BWD, EW_TANH_BWD, EW_INVSIG_BWD, EW_ADD3, EW_AXPBY, EW_COPY = 6, 7, 8, 9, 10, 11
+
+_lib: Optional[ctypes.CDLL] = None
+_backend = "hip"
+
+
+class StcatHipError(RuntimeError):
+    pass
+
+
+def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.argtypes = [_CT[c] for c in sig]
+        fn.restype = ctypes.c_int
+    lib.stcat_version.restype = ctypes.c_int
+    lib.stcat_last_error.restype = ctypes.c_char_p
+    return lib
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise StcatHipError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). stcat_amd has no CPU/PyTorch fallback.")
+        _lib = _bind(ctypes.CDLL(path))
+    return _lib
+
+
+def _use_library_for_testing(path: str) -> None:
+    """TEST HOOK: bind the host-emulator build of the kernels (CPU tensors)."""
+    global _lib, _backend
+    _lib = _bind(ctypes.CDLL(path))
+    _backend = "emu"
+
+
+def backend() -> str:
+    return _backend
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    if _backend == "emu":
+        return None
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def check_tensor(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if _backend == "hip" and not t.is_cuda:
+        raise StcatHipError(f"{name} must live on the GPU (got {t.device}); stcat_amd has no CPU path")
+    if _backend == "emu" and t.is_cuda:
+        raise StcatHipError("emulator backend takes CPU tensors")
+    return t
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.stcat_last_error()
+        raise StcatHipError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")

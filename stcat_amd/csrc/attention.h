@@ -1,0 +1,465 @@
+// Attention kernels (fp32 MFMA 32x32x2, head dim 32).
+//
+// (1) mha_self_*  — joint self-attention over S <= 256 tokens per (frame, head): the
+//     encoder's spatial layers (S = H*W + L + 1, batch = T frames; modal_encoder.py:161-168,
+//     228-242), its temporal layers (S = T+1, batch 1; :180-185) and both decoders'
+//     temporal self-attention over T queries (query_decoder.py:341, 604-610).
+//     One workgroup per (batch, head), one wave per 32-query tile.  K and V of the
+//     (batch, head) live wholly in LDS (<= 67 KB), so softmax is single-pass.  The score
+//     tile is computed TRANSPOSED (S^T = K Q^T): with the 32x32 MFMA C-layout every lane
+//     then owns one query column and 16 keys per tile, so max / sum over keys are in-lane
+//     reductions plus one lane^32 exchange, and the same registers are directly the A
+//     operand of the P·V MFMA (no LDS round trip, no permutes).
+//     Probabilities are kept for backward as Pt[b][h][key][query] (padded to Sp = 32*NT):
+//     with 288 GB of HBM, storing P (<= 103 MB / layer) is cheaper than recomputing it on
+//     the 64-cycle fp32 matrix pipe.
+// (2) attn_q1_*   — the decoders' time-aligned cross-attention: exactly ONE query per
+//     frame against that frame's S' memory tokens (query_decoder.py:386-417, 618-639;
+//     custom MHA attention.py:184-393 with k-dim 64 = [content | position], v-dim 32).
+//     This is GEMV-class and HBM-bound; one wave per (frame, head), lanes over keys.
+#pragma once
+#include "stcat_platform.h"
+
+struct AttnParams {
+  const float* Q;  // [B][S][ldq], head h at column h*32
+  const float* K;
+  const float* V;
+  float* O;          // [B][S][ldo]
+  float* Pt;         // [B][H][Sp][Sp] probabilities, key-major
+  const unsigned char* kpm;  // [B][S], 1 = padded key (-> -inf), or null
+  int B, H, S;
+  int ldq, ldk, ldv, ldo;
+  float scale;
+};
+
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) mha_self_fwd_kernel(AttnParams p) {
+  constexpr int SP = NT * 32, KLD = 33;
+  __shared__ __attribute__((aligned(16))) float Ks[SP * KLD];
+  __shared__ __attribute__((aligned(16))) float Vs[SP * 32];
+  __shared__ float kb[SP];
+  const int t = threadIdx.x, lane = t & 63, qt = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const float* Kg = p.K + (long)b * p.S * p.ldk + h * 32;
+  const float* Vg = p.V + (long)b * p.S * p.ldv + h * 32;
+  for (int i = t; i < SP * 8; i += 64 * NT) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (row < p.S) {
+      kv = stcat_ld4(Kg + (long)row * p.ldk + c4);
+      vv = stcat_ld4(Vg + (long)row * p.ldv + c4);
+    }
+    float* kd = &Ks[row * KLD + c4];
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    stcat_st4(&Vs[row * 32 + c4], vv);
+  }
+  for (int i = t; i < SP; i += 64 * NT)
+    kb[i] = (i < p.S && !(p.kpm && p.kpm[(long)b * p.S + i])) ? 0.f : STCAT_NEG_INF;
+  // this lane's query row, dims hi*16 .. hi*16+15, pre-scaled (attention.py:283-285)
+  const int q = qt * 32 + l31;
+  float qr[16];
+  {
+    const float* Qg = p.Q + ((long)b * p.S + q) * p.ldq + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 v4 = q < p.S ? stcat_ld4(Qg + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qr[c * 4 + 0] = v4.x * p.scale; qr[c * 4 + 1] = v4.y * p.scale;
+      qr[c * 4 + 2] = v4.z * p.scale; qr[c * 4 + 3] = v4.w * p.scale;
+    }
+  }
+  __syncthreads();
+  f32x16 sc[NT];
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s)
+      sc[kt] = STCAT_MFMA_32x32x2(Ks[(kt * 32 + l31) * KLD + hi * 16 + s], qr[s], sc[kt]);
+  }
+  float mx = STCAT_NEG_INF;
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      sc[kt][r] += kb[key];
+      mx = fmaxf(mx, sc[kt][r]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      sc[kt][r] = __expf(sc[kt][r] - mx);
+      sum += sc[kt][r];
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.f / sum;
+  float* Ptg = p.Pt + (long)blockIdx.x * SP * SP;
+  f32x16 o;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = sc[kt][r] * inv;
+      Ptg[(long)key * SP + q] = pr;
+      o = STCAT_MFMA_32x32x2(pr, Vs[key * 32 + l31], o);
+    }
+  }
+  float* Og = p.O + (long)b * p.S * p.ldo + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (qq < p.S) Og[(long)qq * p.ldo] = o[r];
+  }
+}
+
+struct AttnBwdParams {
+  const float* Q;
+  const float* K;
+  const float* V;
+  const float* dO;   // [B][S][ldo]
+  const float* Pt;   // [B][H][Sp][Sp]
+  const float* dW;   // [B][S][S] gradient of the head-averaged weights, or null
+  const float* O;    // [B][S][ldo] forward output (delta_q = dO . O)
+  float* corr;       // [B][H][S] scratch: (1/H) sum_k P dW, only used with dW
+  float* dSt;        // [B][H][Sp][Sp] scratch: scale * dS, key-major
+  float* dQ;         // [B][S][ldg]
+  float* dK;
+  float* dV;
+  int B, H, S;
+  int ldq, ldk, ldv, ldo, ldg, ldgv;  // ldg: row stride of dQ and dK, ldgv: of dV
+  float scale;
+};
+
+// backward, phase 1: one wave per query tile -> dS (stored key-major, pre-multiplied by scale) and dQ
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_kernel(AttnBwdParams p) {
+  constexpr int SP = NT * 32, KLD = 33;
+  __shared__ __attribute__((aligned(16))) float Vs[SP * KLD];  // A operand of dP^T = V dO^T
+  __shared__ __attribute__((aligned(16))) float Ks[SP * 32];   // B operand of dQ = dS K
+  const int t = threadIdx.x, lane = t & 63, qt = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const float* Kg = p.K + (long)b * p.S * p.ldk + h * 32;
+  const float* Vg = p.V + (long)b * p.S * p.ldv + h * 32;
+  for (int i = t; i < SP * 8; i += 64 * NT) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (row < p.S) {
+      kv = stcat_ld4(Kg + (long)row * p.ldk + c4);
+      vv = stcat_ld4(Vg + (long)row * p.ldv + c4);
+    }
+    float* vd = &Vs[row * KLD + c4];
+    vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+    stcat_st4(&Ks[row * 32 + c4], kv);
+  }
+  const int q = qt * 32 + l31;
+  float dor[16];
+  float delta = 0.f;  // delta_q = sum_k P[q,k] dP[q,k] = dO[q,:] . O[q,:]  (+ head-mean-weights term)
+  {
+    const float* g = p.dO + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    const float* og = p.O + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = v4;
+      if (q < p.S) {
+        v4 = stcat_ld4(g + c * 4);
+        o4 = stcat_ld4(og + c * 4);
+      }
+      dor[c * 4 + 0] = v4.x; dor[c * 4 + 1] = v4.y; dor[c * 4 + 2] = v4.z; dor[c * 4 + 3] = v4.w;
+      delta += v4.x * o4.x + v4.y * o4.y + v4.z * o4.z + v4.w * o4.w;
+    }
+  }
+  delta += __shfl_xor(delta, 32);
+  if (p.dW && q < p.S) delta += p.corr[(long)blockIdx.x * p.S + q];
+  __syncthreads();
+  const float* Ptg = p.Pt + (long)blockIdx.x * SP * SP + hi * 4 * SP + q;
+  float* dStg = p.dSt + (long)blockIdx.x * SP * SP + hi * 4 * SP + q;
+  const float invH = 1.f / (float)p.H;
+  f32x16 dq;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x16 dp;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s)
+      dp = STCAT_MFMA_32x32x2(Vs[(kt * 32 + l31) * KLD + hi * 16 + s], dor[s], dp);
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int krel = kt * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi folded into the base pointers
+      const int key = krel + 4 * hi;
+      float dpv = dp[r];
+      if (p.dW && q < p.S && key < p.S) dpv += p.dW[((long)b * p.S + q) * p.S + key] * invH;
+      const float ds = Ptg[(long)krel * SP] * (dpv - delta) * p.scale;
+      dStg[(long)krel * SP] = ds;
+      dq = STCAT_MFMA_32x32x2(ds, Ks[key * 32 + l31], dq);
+    }
+  }
+  float* g = p.dQ + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (qq < p.S) g[(long)qq * p.ldg] = dq[r];
+  }
+}
+
+// backward, phase 2: one wave per key tile -> dV = P^T dO, dK = (scale*dS)^T Q
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams p) {
+  constexpr int SP = NT * 32;
+  __shared__ __attribute__((aligned(16))) float dOs[SP * 32];
+  __shared__ __attribute__((aligned(16))) float Qs[SP * 32];
+  const int t = threadIdx.x, lane = t & 63, kt = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const float* Qg = p.Q + (long)b * p.S * p.ldq + h * 32;
+  const float* Gg = p.dO + (long)b * p.S * p.ldo + h * 32;
+  for (int i = t; i < SP * 8; i += 64 * NT) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
+    if (row < p.S) {
+      qv = stcat_ld4(Qg + (long)row * p.ldq + c4);
+      gv = stcat_ld4(Gg + (long)row * p.ldo + c4);
+    }
+    stcat_st4(&Qs[row * 32 + c4], qv);
+    stcat_st4(&dOs[row * 32 + c4], gv);
+  }
+  __syncthreads();
+  const int key = kt * 32 + l31;  // A-operand row of this lane
+  const float* Prow = p.Pt + (long)blockIdx.x * SP * SP + (long)key * SP + hi * 4;
+  const float* Srow = p.dSt + (long)blockIdx.x * SP * SP + (long)key * SP + hi * 4;
+  f32x16 dv, dk;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+  // reduction over queries in chunks of 8: half `hi` feeds queries qc*8 + hi*4 + e
+  for (int qc = 0; qc < SP / 8; ++qc) {
+    const float4 pv = stcat_ld4(Prow + qc * 8);
+    const float4 sv = stcat_ld4(Srow + qc * 8);
+    const int qb = qc * 8 + hi * 4;
+    dv = STCAT_MFMA_32x32x2(pv.x, dOs[(qb + 0) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.x, Qs[(qb + 0) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.y, dOs[(qb + 1) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.y, Qs[(qb + 1) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.z, dOs[(qb + 2) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.z, Qs[(qb + 2) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.w, dOs[(qb + 3) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.w, Qs[(qb + 3) * 32 + l31], dk);
+  }
+  float* gv = p.dV + (long)b * p.S * p.ldgv + h * 32 + l31;
+  float* gk = p.dK + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (kk < p.S) {
+      gv[(long)kk * p.ldgv] = dv[r];
+      gk[(long)kk * p.ldg] = dk[r];
+    }
+  }
+}
+
+// head-averaged attention weights W[b][q][k] = mean_h P[b][h][q][k]  (nn.MultiheadAttention
+// need_weights=True; consumed only for the time decoder: pipeline.py:84-85)
+__global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H, int S, int SP) {
+  const long n = (long)B * S * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % S), q = (int)((i / S) % S), b = (int)(i / ((long)S * S));
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc += Pt[(((long)b * H + h) * SP + k) * SP + q];
+    W[i] = acc / (float)H;
+  }
+}
+
+// corr[b][h][q] = (1/H) sum_k P[b][h][q][k] * dW[b][q][k]   (softmax-backward delta term of the
+// head-averaged weights gradient; only the time decoder's self-attention has one)
+__global__ void attn_dw_corr_kernel(const float* Pt, const float* dW, float* corr, int B, int H, int S, int SP) {
+  const long n = (long)B * H * S;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % S), h = (int)((i / S) % H), b = (int)(i / ((long)S * H));
+    float acc = 0.f;
+    for (int k = 0; k < S; ++k)
+      acc += Pt[(((long)b * H + h) * SP + k) * SP + q] * dW[((long)b * S + q) * S + k];
+    corr[i] = acc / (float)H;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// one query per frame
+// ---------------------------------------------------------------------------------
+struct AttnQ1Params {
+  const float* q1;  // [B][ldq] (head h at h*32)
+  const float* q2;  // second 32-dim part per head (sine/position part) or null
+  const float* k1;  // [B][S][ldk]
+  const float* k2;  // or null
+  const float* v;   // [B][S][ldv]
+  const unsigned char* kpm;  // [B][S]
+  float* out;       // [B][H*32]
+  float* P;         // [B][H][S]
+  // backward
+  const float* dout;
+  float* dq1;
+  float* dq2;
+  float* dk1;  // [B][S][H*32]
+  float* dk2;
+  float* dv;
+  int B, H, S;
+  int ldq, ldk, ldv;
+  float scale;
+};
+
+#define STCAT_Q1_MAXC 4  // S <= 256
+
+__global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
+  __shared__ float ps[4][STCAT_Q1_MAXC * 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int bh_raw = blockIdx.x * 4 + w;
+  const bool live = bh_raw < p.B * p.H;
+  const int bh = live ? bh_raw : 0;
+  const int b = bh / p.H, h = bh % p.H;
+  float qa[32], qb[32];
+  STCAT_UNROLL
+  for (int c = 0; c < 8; ++c) {
+    float4 v4 = stcat_ld4(p.q1 + (long)b * p.ldq + h * 32 + c * 4);
+    qa[c * 4] = v4.x; qa[c * 4 + 1] = v4.y; qa[c * 4 + 2] = v4.z; qa[c * 4 + 3] = v4.w;
+    float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
+  }
+  float sc[STCAT_Q1_MAXC];
+  float mx = STCAT_NEG_INF;
+  STCAT_UNROLL
+  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
+    const int s = c * 64 + lane;
+    float val = STCAT_NEG_INF;
+    if (s < p.S && !(p.kpm && p.kpm[(long)b * p.S + s])) {
+      const float* kr = p.k1 + ((long)b * p.S + s) * p.ldk + h * 32;
+      float dot = 0.f;
+      STCAT_UNROLL
+      for (int d4 = 0; d4 < 8; ++d4) {
+        float4 kv = stcat_ld4(kr + d4 * 4);
+        dot += kv.x * qa[d4 * 4] + kv.y * qa[d4 * 4 + 1] + kv.z * qa[d4 * 4 + 2] + kv.w * qa[d4 * 4 + 3];
+      }
+      if (p.k2) {
+        const float* kr2 = p.k2 + ((long)b * p.S + s) * p.ldk + h * 32;
+        STCAT_UNROLL
+        for (int d4 = 0; d4 < 8; ++d4) {
+          float4 kv = stcat_ld4(kr2 + d4 * 4);
+          dot += kv.x * qb[d4 * 4] + kv.y * qb[d4 * 4 + 1] + kv.z * qb[d4 * 4 + 2] + kv.w * qb[d4 * 4 + 3];
+        }
+      }
+      val = dot * p.scale;
+    }
+    sc[c] = val;
+    mx = fmaxf(mx, val);
+  }
+  mx = stcat_wave_max(mx);
+  float sum = 0.f;
+  STCAT_UNROLL
+  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
+    sc[c] = __expf(sc[c] - mx);
+    sum += sc[c];
+  }
+  sum = stcat_wave_sum(sum);
+  const float inv = 1.f / sum;
+  STCAT_UNROLL
+  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
+    const int s = c * 64 + lane;
+    const float pr = sc[c] * inv;
+    ps[w][s] = pr;
+    if (live && s < p.S) p.P[(long)bh * p.S + s] = pr;
+  }
+  __syncthreads();
+  float o = 0.f;
+  const float* vb = p.v + (long)b * p.S * p.ldv + h * 32 + l31;
+  for (int s = hi; s < p.S; s += 2) o += ps[w][s] * vb[(long)s * p.ldv];
+  o += __shfl_xor(o, 32);
+  if (live && hi == 0) p.out[(long)b * p.H * 32 + h * 32 + l31] = o;
+}
+
+__global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
+  __shared__ float dss[4][STCAT_Q1_MAXC * 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int bh_raw = blockIdx.x * 4 + w;
+  const bool live = bh_raw < p.B * p.H;
+  const int bh = live ? bh_raw : 0;
+  const int b = bh / p.H, h = bh % p.H;
+  const int HD = p.H * 32;
+  float go[32], qa[32], qb[32];
+  STCAT_UNROLL
+  for (int c = 0; c < 8; ++c) {
+    float4 g4 = stcat_ld4(p.dout + (long)b * HD + h * 32 + c * 4);
+    go[c * 4] = g4.x; go[c * 4 + 1] = g4.y; go[c * 4 + 2] = g4.z; go[c * 4 + 3] = g4.w;
+    float4 v4 = stcat_ld4(p.q1 + (long)b * p.ldq + h * 32 + c * 4);
+    qa[c * 4] = v4.x; qa[c * 4 + 1] = v4.y; qa[c * 4 + 2] = v4.z; qa[c * 4 + 3] = v4.w;
+    float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
+  }
+  float pr[STCAT_Q1_MAXC], dp[STCAT_Q1_MAXC];
+  float delta = 0.f;
+  STCAT_UNROLL
+  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
+    const int s = c * 64 + lane;
+    pr[c] = 0.f;
+    dp[c] = 0.f;
+    if (s < p.S) {
+      pr[c] = p.P[(long)bh * p.S + s];
+      const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
+      float dot = 0.f;
+      STCAT_UNROLL
+      for (int d4 = 0; d4 < 8; ++d4) {
+        float4 vv = stcat_ld4(vr + d4 * 4);
+        dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
+      }
+      dp[c] = dot;
+      delta += pr[c] * dot;
+    }
+  }
+  delta = stcat_wave_sum(delta);
+  STCAT_UNROLL
+  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
+    const int s = c * 64 + lane;
+    const float ds = pr[c] * (dp[c] - delta) * p.scale;
+    dss[w][s] = ds;
+    if (live && s < p.S) {
+      float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
+      float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
+      STCAT_UNROLL
+      for (int d4 = 0; d4 < 8; ++d4) {
+        stcat_st4(gv + d4 * 4, make_float4(pr[c] * go[d4 * 4], pr[c] * go[d4 * 4 + 1], pr[c] * go[d4 * 4 + 2],
+                                           pr[c] * go[d4 * 4 + 3]));
+        stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2],
+                                            ds * qa[d4 * 4 + 3]));
+      }
+      if (p.dk2) {
+        float* gk2 = p.dk2 + ((long)b * p.S + s) * HD + h * 32;
+        STCAT_UNROLL
+        for (int d4 = 0; d4 < 8; ++d4)
+          stcat_st4(gk2 + d4 * 4, make_float4(ds * qb[d4 * 4], ds * qb[d4 * 4 + 1], ds * qb[d4 * 4 + 2],
+                                              ds * qb[d4 * 4 + 3]));
+      }
+    }
+  }
+  __syncthreads();
+  float a1 = 0.f, a2 = 0.f;
+  const float* k1b = p.k1 + (long)b * p.S * p.ldk + h * 32 + l31;
+  const float* k2b = p.k2 ? p.k2 + (long)b * p.S * p.ldk + h * 32 + l31 : nullptr;
+  for (int s = hi; s < p.S; s += 2) {
+    const float ds = dss[w][s];
+    a1 += ds * k1b[(long)s * p.ldk];
+    if (k2b) a2 += ds * k2b[(long)s * p.ldk];
+  }
+  a1 += __shfl_xor(a1, 32);
+  a2 += __shfl_xor(a2, 32);
+  if (live && hi == 0) {
+    p.dq1[(long)b * HD + h * 32 + l31] = a1;
+    if (p.dq2) p.dq2[(long)b * HD + h * 32 + l31] = a2;
+  }
+}

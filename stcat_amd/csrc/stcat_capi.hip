@@ -1,0 +1,424 @@
+// extern "C" boundary of libstcat_hip.so (declared in include/stcat_hip.h).
+// Plain pointers and sizes only; no torch types.  Built by hipcc for gfx950
+// (and, with -DSTCAT_EMU, by host clang against tests/emu/hip_emu.h for index-logic tests).
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/stcat_hip.h"
+#include "attention.h"
+#include "igemm.h"
+#include "pointwise.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+#ifdef STCAT_EMU
+inline int launch_status() { return 0; }
+#else
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "HIP launch failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+#endif
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline int grid_for(long n, int per_block, int cap = 4096) {
+  long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// tile choice: prefer the biggest tile that still fills the 256 CUs a few times over
+int g_force_bm = 0, g_force_bn = 0;  // stcat_debug_force_tile
+void pick_tile(int M, int N, int& BM, int& BN) {
+  if (g_force_bm && N % g_force_bn == 0) {
+    BM = g_force_bm;
+    BN = g_force_bn;
+    return;
+  }
+  const int cands[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  long best = -1;
+  BM = 64;
+  BN = 64;
+  for (auto& c : cands) {
+    if (N % c[1] != 0) continue;
+    if (c[0] == 128 && M <= 64) continue;
+    const long blocks = (long)cdiv(M, c[0]) * (N / c[1]);
+    if (blocks >= 600) {
+      BM = c[0];
+      BN = c[1];
+      return;
+    }
+    if (blocks > best) {
+      best = blocks;
+      BM = c[0];
+      BN = c[1];
+    }
+  }
+}
+
+int launch_fwd(const IgemmParams& p, hipStream_t st) {
+  int BM, BN;
+  pick_tile(p.M, p.N, BM, BN);
+  const int blocks = cdiv(p.M, BM) * (p.N / BN);
+  if (BM == 128 && BN == 128) {
+    STCAT_LAUNCH((igemm_fwd_kernel<128, 128>), dim3(blocks), dim3(256), 0, st, p);
+  } else if (BM == 128) {
+    STCAT_LAUNCH((igemm_fwd_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, p);
+  } else {
+    STCAT_LAUNCH((igemm_fwd_kernel<64, 64>), dim3(blocks), dim3(256), 0, st, p);
+  }
+  return launch_status();
+}
+
+int launch_dgrad(const IgemmParams& p, hipStream_t st) {
+  int BM, BN;
+  pick_tile(p.M, p.N, BM, BN);
+  const int blocks = cdiv(p.M, BM) * (p.N / BN);
+  if (BM == 128 && BN == 128) {
+    STCAT_LAUNCH((igemm_dgrad_kernel<128, 128>), dim3(blocks), dim3(256), 0, st, p);
+  } else if (BM == 128) {
+    STCAT_LAUNCH((igemm_dgrad_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, p);
+  } else {
+    STCAT_LAUNCH((igemm_dgrad_kernel<64, 64>), dim3(blocks), dim3(256), 0, st, p);
+  }
+  return launch_status();
+}
+
+// rows = output rows (Cout / N_lin), cols = output columns (KH*KW*Cin / K_lin), red = reduction length (pixels)
+int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
+  const bool big = (rows % 128 == 0) && (p.g.C % 128 == 0) && g_force_bm != 64;
+  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  const int tiles = (rows / BM) * (cols / BN);
+  int nsplit = cdiv(1024, tiles);
+  const int max_split = cdiv(red, 64);
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int chunk = cdiv(red, nsplit);
+  chunk = ((chunk + 15) / 16) * 16;
+  nsplit = cdiv(red, chunk);
+  p.M = rows;
+  p.N = cols;
+  p.K = red;
+  p.k_chunk = chunk;
+  if (big) {
+    STCAT_LAUNCH((igemm_wgrad_kernel<128, 128>), dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
+  } else {
+    STCAT_LAUNCH((igemm_wgrad_kernel<64, 64>), dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
+  }
+  return launch_status();
+}
+
+IgemmGeom conv_geom_fwd(int H, int W, int C, int ld, int OH, int OW, int KH, int KW, int stride, int pad) {
+  IgemmGeom g;
+  g.H = H; g.W = W; g.C = C; g.ld = ld; g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW;
+  g.mul = stride; g.off = -pad; g.sgn = 1; g.div = 1;
+  return g;
+}
+}  // namespace
+
+extern "C" {
+
+int stcat_version(void) { return 100; }
+int stcat_debug_force_tile(int bm, int bn) {
+  const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
+  if (!ok) return fail("debug_force_tile: unsupported tile %dx%d", bm, bn);
+  g_force_bm = bm;
+  g_force_bn = bn;
+  return 0;
+}
+const char* stcat_last_error(void) { return g_err; }
+
+int stcat_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                         float* bias, int C, float eps, void* stream) {
+  if (C <= 0) return fail("frozen_bn_fold: C=%d", C);
+  STCAT_LAUNCH(frozen_bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, w, b, rm, rv, scale,
+               bias, C, eps);
+  return launch_status();
+}
+
+int stcat_stem_fwd(const float* frames, const float* w, const float* scale, const float* bias, float* y, int n,
+                   int H, int W, void* stream) {
+  if (n <= 0 || H < 7 || W < 7) return fail("stem_fwd: bad shape n=%d H=%d W=%d", n, H, W);
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  IgemmParams p = {};
+  p.A = frames; p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = nullptr;
+  p.M = n * OH * OW; p.N = 64; p.K = 147; p.ldb = 147; p.ldc = 64; p.ldr = 0;
+  p.c_group = p.M; p.c_group_stride = 0; p.relu = 1;
+  p.g = conv_geom_fwd(H, W, 3, 0, OH, OW, 7, 7, 2, 3);
+  STCAT_LAUNCH(igemm_stem_kernel, dim3(cdiv(p.M, 128)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+int stcat_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream) {
+  if (C % 4 != 0 || !aligned16(x) || !aligned16(y)) return fail("maxpool: C %% 4 != 0 or unaligned");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)n * OH * OW * (C / 4);
+  STCAT_LAUNCH(maxpool3x3s2_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, n, H,
+               W, C, OH, OW);
+  return launch_status();
+}
+
+int stcat_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* res,
+                   float* y, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   int relu, void* stream) {
+  if (Cin % 16 != 0 || Cout % 64 != 0) return fail("conv_fwd: need Cin %% 16 == 0 and Cout %% 64 == 0 (%d, %d)", Cin, Cout);
+  if (!aligned16(x) || !aligned16(w)) return fail("conv_fwd: operands must be 16-byte aligned");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  IgemmParams p = {};
+  p.A = x; p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = res;
+  p.M = n * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
+  p.c_group = p.M; p.c_group_stride = 0; p.relu = relu;
+  p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
+  return launch_fwd(p, (hipStream_t)stream);
+}
+
+int stcat_conv_dgrad(const float* g, const float* w, const float* add, float* dx, int n, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  if (Cout % 16 != 0 || Cin % 64 != 0) return fail("conv_dgrad: need Cout %% 16 == 0 and Cin %% 64 == 0 (%d, %d)", Cout, Cin);
+  if (!aligned16(g) || !aligned16(w)) return fail("conv_dgrad: operands must be 16-byte aligned");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  IgemmParams p = {};
+  p.A = g; p.B = w; p.C = dx; p.res = add;
+  p.M = n * H * W; p.N = Cin; p.K = KH * KW * Cout; p.ldb = KH * KW * Cin; p.ldc = Cin; p.ldr = Cin;
+  p.c_group = p.M; p.relu = 0;
+  // gathered tensor = g [n,OH,OW,Cout]; rows enumerate input pixels (hi, wi): ho = (hi + pad - kh) / stride
+  IgemmGeom q;
+  q.H = OH; q.W = OW; q.C = Cout; q.ld = Cout; q.OH = H; q.OW = W; q.KH = KH; q.KW = KW;
+  q.mul = 1; q.off = pad; q.sgn = -1; q.div = stride;
+  p.g = q;
+  return launch_dgrad(p, (hipStream_t)stream);
+}
+
+int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream) {
+  if (Cout % 64 != 0 || Cin % 64 != 0) return fail("conv_wgrad: need Cout, Cin %% 64 == 0 (%d, %d)", Cout, Cin);
+  if (!aligned16(g) || !aligned16(x)) return fail("conv_wgrad: operands must be 16-byte aligned");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  IgemmParams p = {};
+  p.A = g; p.B = x; p.C = dw; p.ldb = Cout; p.ldc = KH * KW * Cin;
+  p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
+  return launch_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
+}
+
+int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G, float* dres, long n, int C,
+                  int relu, void* stream) {
+  if (n % 4 != 0 || C % 4 != 0) return fail("act_bwd: n and C must be multiples of 4");
+  STCAT_LAUNCH(act_bwd_kernel, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dy, y, scale, G,
+               dres, n / 4, C, relu);
+  return launch_status();
+}
+
+int stcat_pos_sine_2d(const unsigned char* mask, const float* dimt, float* pos, int n, int h, int w, void* stream) {
+  const long total = (long)n * h * w * 256;
+  STCAT_LAUNCH(pos_sine_2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, mask, dimt, pos, n,
+               h, w);
+  return launch_status();
+}
+
+int stcat_sine_embed_fwd(const float* anchor, const float* dimt, float* out, int M, void* stream) {
+  STCAT_LAUNCH(sine_embed_fwd_kernel, dim3(grid_for((long)M * 512, 256)), dim3(256), 0, (hipStream_t)stream, anchor,
+               dimt, out, M);
+  return launch_status();
+}
+
+int stcat_sine_embed_bwd(const float* anchor, const float* dimt, const float* dout, float* danchor, int M,
+                         void* stream) {
+  STCAT_LAUNCH(sine_embed_bwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, anchor, dimt, dout,
+               danchor, M);
+  return launch_status();
+}
+
+int stcat_linear_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                     int K, int ldx, int ldy, int ldr, int relu, int c_group, long c_group_stride, void* stream) {
+  if (N % 64 != 0 || K % 16 != 0) return fail("linear_fwd: need N %% 64 == 0, K %% 16 == 0 (N=%d K=%d)", N, K);
+  if (ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return fail("linear_fwd: x/w must be 16-byte aligned rows");
+  if (M <= 0) return fail("linear_fwd: M=%d", M);
+  IgemmParams p = {};
+  p.A = x; p.B = w; p.C = y; p.scale = nullptr; p.bias = bias; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = ldy; p.ldr = ldr;
+  p.c_group = c_group > 0 ? c_group : M;
+  p.c_group_stride = (int)c_group_stride;
+  p.relu = relu;
+  p.g = conv_geom_fwd(1, 1, K, ldx, 1, 1, 1, 1, 1, 0);
+  return launch_fwd(p, (hipStream_t)stream);
+}
+
+int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
+                       int lddx, void* stream) {
+  if (K % 64 != 0 || N % 16 != 0) return fail("linear_dgrad: need K %% 64 == 0, N %% 16 == 0 (N=%d K=%d)", N, K);
+  if (ldg % 4 != 0 || !aligned16(g) || !aligned16(w)) return fail("linear_dgrad: g/w must be 16-byte aligned rows");
+  IgemmParams p = {};
+  p.A = g; p.B = w; p.C = dx; p.res = add;
+  p.M = M; p.N = K; p.K = N; p.ldb = K; p.ldc = lddx; p.ldr = lddx;
+  p.c_group = M; p.relu = 0;
+  IgemmGeom q;
+  q.H = 1; q.W = 1; q.C = N; q.ld = ldg; q.OH = 1; q.OW = 1; q.KH = 1; q.KW = 1;
+  q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
+  p.g = q;
+  return launch_dgrad(p, (hipStream_t)stream);
+}
+
+int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, int K, int ldg, int ldx,
+                       void* stream) {
+  if (N % 64 != 0 || K % 64 != 0) return fail("linear_wgrad: need N, K %% 64 == 0 (N=%d K=%d)", N, K);
+  if (ldg % 4 != 0 || ldx % 4 != 0 || !aligned16(g) || !aligned16(x)) return fail("linear_wgrad: unaligned");
+  IgemmParams p = {};
+  p.A = g; p.B = x; p.C = dw; p.ldb = ldg; p.ldc = K;
+  p.g = conv_geom_fwd(1, 1, K, ldx, 1, 1, 1, 1, 1, 0);
+  return launch_wgrad(p, N, K, M, (hipStream_t)stream);
+}
+
+int stcat_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,
+                           void* stream) {
+  if (N > 16 || K % 4 != 0) return fail("small_linear_fwd: need N <= 16, K %% 4 == 0 (N=%d K=%d)", N, K);
+  STCAT_LAUNCH(small_linear_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N,
+               K);
+  return launch_status();
+}
+
+int stcat_small_linear_bwd(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int M,
+                           int N, int K, void* stream) {
+  if (N > 16) return fail("small_linear_bwd: N=%d > 16", N);
+  if (dx) {
+    STCAT_LAUNCH(small_linear_dx_kernel, dim3(grid_for((long)M * K, 256)), dim3(256), 0, (hipStream_t)stream, g, w, dx,
+                 M, N, K);
+  }
+  if (dw) {
+    STCAT_LAUNCH(small_linear_dw_kernel, dim3(grid_for((long)N * K, 256)), dim3(256), 0, (hipStream_t)stream, g, x, dw,
+                 db, M, N, K);
+  }
+  return launch_status();
+}
+
+int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream) {
+  if (M <= 0 || N <= 0) return fail("colsum: M=%d N=%d", M, N);
+  int rows = cdiv(M, 512);
+  if (rows < 8) rows = 8;
+  STCAT_LAUNCH(colsum_kernel, dim3(cdiv(M, rows), cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, M, N,
+               rows);
+  return launch_status();
+}
+
+int stcat_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int M, int D, float eps, void* stream) {
+  if (D != 256) return fail("layernorm: D must be 256 (got %d)", D);
+  STCAT_LAUNCH(layernorm_fwd_kernel, dim3(grid_for(M, 4, 2048)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
+               beta, y, mean, rstd, M, eps);
+  return launch_status();
+}
+
+int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
+                        const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D, void* stream) {
+  if (D != 256) return fail("layernorm: D must be 256 (got %d)", D);
+  STCAT_LAUNCH(layernorm_bwd_kernel, dim3(grid_for(M, 16, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, res, gamma,
+               mean, rstd, dz, dgamma, dbeta, M);
+  return launch_status();
+}
+
+int stcat_ew(int op, const float* a, const float* b, const float* c, float* out, long n, long bmod, float alpha,
+             float beta, void* stream) {
+  if (n <= 0) return fail("ew: n=%ld", n);
+  if (bmod <= 0) bmod = n;
+  STCAT_LAUNCH(ew_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, op, a, b, c, out, n, bmod,
+               alpha, beta);
+  return launch_status();
+}
+
+#define STCAT_NT_SWITCH(NT_, CALL)                                   \
+  switch (NT_) {                                                     \
+    case 1: { constexpr int NT = 1; CALL; } break;                   \
+    case 2: { constexpr int NT = 2; CALL; } break;                   \
+    case 3: { constexpr int NT = 3; CALL; } break;                   \
+    case 4: { constexpr int NT = 4; CALL; } break;                   \
+    case 5: { constexpr int NT = 5; CALL; } break;                   \
+    case 6: { constexpr int NT = 6; CALL; } break;                   \
+    case 7: { constexpr int NT = 7; CALL; } break;                   \
+    case 8: { constexpr int NT = 8; CALL; } break;                   \
+    default: return fail("mha_self: S=%d exceeds 256 tokens", S);    \
+  }
+
+int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o,
+                       float* pt, int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                       void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0) return fail("mha_self_fwd: bad shape");
+  if ((ldq | ldk | ldv) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v))
+    return fail("mha_self_fwd: q/k/v must be 16-byte aligned with ld %% 4 == 0");
+  AttnParams p = {q, k, v, o, pt, kpm, B, H, S, ldq, ldk, ldv, ldo, scale};
+  const int nt = cdiv(S, 32);
+  STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_fwd_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
+  return launch_status();
+}
+
+int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                       const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
+                       int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0) return fail("mha_self_bwd: bad shape");
+  if ((ldq | ldk | ldv | ldo) % 4 != 0) return fail("mha_self_bwd: ld %% 4 != 0");
+  if (dw && !corr) return fail("mha_self_bwd: dw given without corr scratch");
+  AttnBwdParams p = {};
+  p.Q = q; p.K = k; p.V = v; p.dO = dout; p.Pt = pt; p.dW = dw; p.O = out; p.corr = corr; p.dSt = dst;
+  p.dQ = dq; p.dK = dk; p.dV = dv; p.B = B; p.H = H; p.S = S;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldg = ldg; p.ldgv = ldgv; p.scale = scale;
+  const int nt = cdiv(S, 32);
+  if (dw) {
+    STCAT_LAUNCH(attn_dw_corr_kernel, dim3(grid_for((long)B * H * S, 256)), dim3(256), 0, (hipStream_t)stream, pt, dw,
+                 corr, B, H, S, nt * 32);
+  }
+  STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_bwd_dq_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
+  int rc = launch_status();
+  if (rc) return rc;
+  STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_bwd_dkv_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
+  return launch_status();
+}
+
+int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, void* stream) {
+  const int SP = cdiv(S, 32) * 32;
+  STCAT_LAUNCH(attn_weights_mean_kernel, dim3(grid_for((long)B * S * S, 256)), dim3(256), 0, (hipStream_t)stream, pt, w,
+               B, H, S, SP);
+  return launch_status();
+}
+
+int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
+                      const unsigned char* kpm, float* out, float* P, int B, int H, int S, int ldq, int ldk,
+                      int ldv, float scale, void* stream) {
+  if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
+  if ((ldq | ldk | ldv) % 4 != 0) return fail("attn_q1: ld %% 4 != 0");
+  AttnQ1Params p = {};
+  p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.kpm = kpm; p.out = out; p.P = P;
+  p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
+  STCAT_LAUNCH(attn_q1_fwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
+                      const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
+                      int B, int H, int S, int ldq, int ldk, int ldv, float scale, void* stream) {
+  if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
+  AttnQ1Params p = {};
+  p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.P = const_cast<float*>(P); p.dout = dout;
+  p.dq1 = dq1; p.dq2 = dq2; p.dk1 = dk1; p.dk2 = dk2; p.dv = dv;
+  p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
+  STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out, int b, int T, void* stream) {
+  if (T <= 0 || T > 1024) return fail("temporal_map_argmax: T=%d out of range (1..1024)", T);
+  STCAT_LAUNCH(temporal_map_argmax_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, sted, durations, out, T);
+  return launch_status();
+}
+
+}  // extern "C"

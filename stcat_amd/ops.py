@@ -1,0 +1,543 @@
+"""Autograd operators of the STCAT hot path, each a thin host wrapper around the
+HIP C ABI (include/stcat_hip.h).  PyTorch supplies device memory, streams and the
+autograd tape; every arithmetic kernel is ours.  Token tensors are row-major
+[rows, features]; images are NHWC.  There is no fallback: if the library is
+missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+_f32 = torch.float32
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None:
+            L.check_tensor(t)
+            if t.dtype != _f32 and t.dtype not in (torch.uint8, torch.bool, torch.int32):
+                raise L.StcatHipError(f"unsupported dtype {t.dtype}")
+
+
+def _empty(like: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.empty(shape, device=like.device, dtype=_f32)
+
+
+def _zeros(like: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.zeros(shape, device=like.device, dtype=_f32)
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
+
+
+_DIMT = {}
+
+
+def dim_t(device) -> torch.Tensor:
+    """10000^(2*floor(i/2)/128), i < 128, computed in fp32 on the host exactly as the
+    reference does (net_utils.py:34-35, vision_model/position_encoding.py:82-84)."""
+    key = str(device)
+    if key not in _DIMT:
+        i = torch.arange(128, dtype=torch.float32)
+        _DIMT[key] = (10000 ** (2 * torch.div(i, 2, rounding_mode="floor") / 128)).to(device)
+    return _DIMT[key]
+
+
+# ------------------------------------------------------------------------------------
+# raw (no autograd) wrappers
+# ------------------------------------------------------------------------------------
+def ew(op: int, a, b=None, c=None, bmod: int = 0, alpha: float = 1.0, beta: float = 1.0, out=None):
+    a = _c(a)
+    b = _c(b)
+    c = _c(c)
+    _chk(a, b, c)
+    out = torch.empty_like(a) if out is None else out
+    L.call("stcat_ew", op, a.data_ptr(), L._ptr(b), L._ptr(c), out.data_ptr(), a.numel(), bmod, alpha, beta,
+           L.stream_of(a))
+    return out
+
+
+def colsum(a2d: torch.Tensor, b2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+    M, N = a2d.shape
+    out = _zeros(a2d, N)
+    L.call("stcat_colsum", a2d.data_ptr(), L._ptr(b2d), out.data_ptr(), M, N, L.stream_of(a2d))
+    return out
+
+
+def linear_fwd_raw(x2d, w, bias, res2d=None, relu=False, out=None, ldy=None, c_group=0, c_group_stride=0):
+    M, K = x2d.shape
+    N = w.shape[0]
+    _chk(x2d, w, bias, res2d)
+    if out is None:
+        out = _empty(x2d, M, N)
+    ldy = N if ldy is None else ldy
+    if N % 64 == 0:
+        L.call("stcat_linear_fwd", x2d.data_ptr(), w.data_ptr(), L._ptr(bias), L._ptr(res2d), out.data_ptr(), M, N, K,
+               x2d.stride(0), ldy, (res2d.stride(0) if res2d is not None else 0), int(relu), c_group, c_group_stride,
+               L.stream_of(x2d))
+    else:
+        assert res2d is None and not relu and c_group == 0 and x2d.is_contiguous()
+        L.call("stcat_small_linear_fwd", x2d.data_ptr(), w.data_ptr(), L._ptr(bias), out.data_ptr(), M, N, K,
+               L.stream_of(x2d))
+    return out
+
+
+def act_bwd_raw(dy, y, scale, want_g=True, want_res=False, relu=True):
+    dy = _c(dy)
+    n = dy.numel()
+    C = dy.shape[-1]
+    G = torch.empty_like(dy) if want_g else None
+    R = torch.empty_like(dy) if want_res else None
+    L.call("stcat_act_bwd", dy.data_ptr(), L._ptr(y), L._ptr(scale), L._ptr(G), L._ptr(R), n, C, int(relu),
+           L.stream_of(dy))
+    return G, R
+
+
+# ------------------------------------------------------------------------------------
+# Linear (+bias, +residual, +ReLU)
+# ------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = relu?(x W^T + b + res)  — torch.nn.Linear call sites of the grounding model
+    (modal_encoder.py:214-216, query_decoder.py:262-284, net_utils.py:13-15)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, relu):
+        shp = x.shape
+        x2 = _c(x.reshape(-1, shp[-1]))
+        w = _c(w)
+        r2 = _c(res.reshape(-1, w.shape[0])) if res is not None else None
+        y = linear_fwd_raw(x2, w, _c(b), r2, relu)
+        ctx.relu = relu
+        ctx.has_res = res is not None
+        ctx.has_b = b is not None
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.xshape = shp
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        N, K = w.shape
+        g = _c(dy.reshape(-1, N))
+        if ctx.relu:
+            g, _ = act_bwd_raw(g, y, None, want_g=True, relu=True)
+        M = g.shape[0]
+        st = L.stream_of(g)
+        dx = dw = db = None
+        if N % 64 == 0:
+            if ctx.needs_input_grad[0]:
+                dx = _empty(g, M, K)
+                L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), M, N, K, N, K, st)
+            if ctx.needs_input_grad[1]:
+                dw = _zeros(g, N, K)
+                L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), M, N, K, N, K, st)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = colsum(g)
+        else:
+            dx = _empty(g, M, K) if ctx.needs_input_grad[0] else None
+            dw = _empty(g, N, K) if ctx.needs_input_grad[1] else None
+            db = _empty(g, N) if (ctx.has_b and dw is not None) else None
+            L.call("stcat_small_linear_bwd", g.data_ptr(), x2.data_ptr(), w.data_ptr(), L._ptr(dx), L._ptr(dw),
+                   L._ptr(db), M, N, K, st)
+        dres = g.view(*ctx.xshape[:-1], N) if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db, dres, None
+
+
+def linear(x, w, b=None, res=None, relu=False):
+    return LinearFn.apply(x, w, b, res, relu)
+
+
+# ------------------------------------------------------------------------------------
+# LayerNorm(x + res)
+# ------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        shp = x.shape
+        D = shp[-1]
+        x2 = _c(x.reshape(-1, D))
+        r2 = _c(res.reshape(-1, D)) if res is not None else None
+        _chk(x2, r2, gamma, beta)
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = _empty(x2, M)
+        rstd = _empty(x2, M)
+        L.call("stcat_layernorm_fwd", x2.data_ptr(), L._ptr(r2), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+               mean.data_ptr(), rstd.data_ptr(), M, D, eps, L.stream_of(x2))
+        ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+        ctx.xshape = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, gamma, mean, rstd = ctx.saved_tensors
+        M, D = x2.shape
+        g = _c(dy.reshape(M, D))
+        dz = torch.empty_like(x2)
+        dgam = _zeros(x2, D)
+        dbet = _zeros(x2, D)
+        L.call("stcat_layernorm_bwd", g.data_ptr(), x2.data_ptr(), L._ptr(r2), gamma.data_ptr(), mean.data_ptr(),
+               rstd.data_ptr(), dz.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), M, D, L.stream_of(g))
+        dzv = dz.view(ctx.xshape)
+        return dzv, (dzv if r2 is not None else None), dgam, dbet, None
+
+
+def layer_norm(x, gamma, beta, res=None, eps: float = 1e-5):
+    return LayerNormFn.apply(x, res, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------
+# element-wise glue with gradients
+# ------------------------------------------------------------------------------------
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        assert a.shape == b.shape
+        return ew(L.EW_ADD, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class Add3Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        assert a.shape == b.shape == c.shape
+        return ew(L.EW_ADD3, a, b, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, g
+
+
+class AddConstFn(Function):
+    """a + c where c carries no gradient and may be a row-broadcast [D] / [rows,D] block."""
+
+    @staticmethod
+    def forward(ctx, a, c):
+        assert a.numel() % c.numel() == 0
+        return ew(L.EW_ADD, a, c, bmod=c.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class MulFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        assert a.shape == b.shape
+        ctx.save_for_backward(a, b)
+        return ew(L.EW_MUL, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        return ew(L.EW_MUL, g, b), ew(L.EW_MUL, g, a)
+
+
+class AffineRowsFn(Function):
+    """x[M,D] * gamma[D] + beta[D]  (template generator FiLM, query_decoder.py:465-468)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        M, D = x.shape
+        ctx.save_for_backward(x, gamma)
+        t = ew(L.EW_MUL, x, gamma, bmod=D)
+        return ew(L.EW_ADD, t, beta, bmod=D, out=t)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma = ctx.saved_tensors
+        g = _c(g)
+        D = x.shape[1]
+        return ew(L.EW_MUL, g, gamma, bmod=D), colsum(g, _c(x)), colsum(g)
+
+
+class UnaryFn(Function):
+    @staticmethod
+    def forward(ctx, x, fop, bop, save_out):
+        y = ew(fop, x)
+        ctx.bop = bop
+        ctx.save_for_backward(y if save_out else _c(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return ew(ctx.bop, _c(g), s), None, None, None
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+def add3(a, b, c):
+    return Add3Fn.apply(a, b, c)
+
+
+def add_const(a, c):
+    return AddConstFn.apply(a, c)
+
+
+def mul(a, b):
+    return MulFn.apply(a, b)
+
+
+def affine_rows(x, gamma, beta):
+    return AffineRowsFn.apply(x, gamma, beta)
+
+
+def sigmoid(x):
+    return UnaryFn.apply(x, L.EW_SIGMOID, L.EW_SIGMOID_BWD, True)
+
+
+def tanh(x):
+    return UnaryFn.apply(x, L.EW_TANH, L.EW_TANH_BWD, True)
+
+
+def inverse_sigmoid(x):
+    """models/net_utils.py:59-63."""
+    return UnaryFn.apply(x, L.EW_INVSIG, L.EW_INVSIG_BWD, False)
+
+
+class SineEmbedFn(Function):
+    """gen_sineembed_for_position — models/net_utils.py:29-56."""
+
+    @staticmethod
+    def forward(ctx, anchor):
+        a2 = _c(anchor.reshape(-1, 4))
+        _chk(a2)
+        M = a2.shape[0]
+        out = _empty(a2, M, 512)
+        L.call("stcat_sine_embed_fwd", a2.data_ptr(), dim_t(a2.device).data_ptr(), out.data_ptr(), M, L.stream_of(a2))
+        ctx.save_for_backward(a2)
+        ctx.shp = anchor.shape
+        return out.view(*anchor.shape[:-1], 512)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a2,) = ctx.saved_tensors
+        M = a2.shape[0]
+        g2 = _c(g.reshape(M, 512))
+        da = torch.empty_like(a2)
+        L.call("stcat_sine_embed_bwd", a2.data_ptr(), dim_t(a2.device).data_ptr(), g2.data_ptr(), da.data_ptr(), M,
+               L.stream_of(a2))
+        return da.view(ctx.shp)
+
+
+def sine_embed(anchor):
+    return SineEmbedFn.apply(anchor)
+
+
+def pos_sine_2d(mask: torch.Tensor) -> torch.Tensor:
+    """PositionEmbeddingSine(128, normalize=True): mask [n,h,w] bool -> [n, h*w, 256] (token-major)."""
+    n, h, w = mask.shape
+    m8 = _c(mask.to(torch.uint8))
+    L.check_tensor(m8)
+    pos = torch.empty(n, h * w, 256, device=mask.device, dtype=_f32)
+    L.call("stcat_pos_sine_2d", m8.data_ptr(), dim_t(mask.device).data_ptr(), pos.data_ptr(), n, h, w,
+           L.stream_of(pos))
+    return pos
+
+
+# ------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------
+def _ld3(t: torch.Tensor) -> int:
+    """row stride of a [B,S,D] view whose last dim is dense and whose batch stride is S*ld."""
+    B, S, D = t.shape
+    assert t.stride(2) == 1 and (B == 1 or t.stride(0) == S * t.stride(1)), "unsupported view"
+    return t.stride(1)
+
+
+class MhaSelfFn(Function):
+    """softmax(scale * q k^T + key_padding) v per (batch, head), head dim 32 — the core of
+    torch.nn.MultiheadAttention after its in-projection (modal_encoder.py:236; query_decoder.py:341, 604).
+    q, k, v: [B,S,256] views (e.g. column slices of a packed projection).  Returns (out, weights|None)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kpm, scale, need_weights, packed_qk):
+        B, S, D = v.shape
+        H = D // 32
+        _chk(q, k, v)
+        kp = None
+        if kpm is not None:
+            kp = _c(kpm.to(torch.uint8))
+        SP = ((S + 31) // 32) * 32
+        o = _empty(v, B, S, D)
+        pt = _empty(v, B, H, SP, SP)
+        L.call("stcat_mha_self_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), pt.data_ptr(),
+               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, L.stream_of(v))
+        wts = None
+        if need_weights:
+            wts = _empty(v, B, S, S)
+            L.call("stcat_attn_weights_mean", pt.data_ptr(), wts.data_ptr(), B, H, S, L.stream_of(v))
+        ctx.save_for_backward(q, k, v, o, pt)
+        ctx.scale = scale
+        ctx.packed_qk = packed_qk
+        ctx.need_weights = need_weights
+        if need_weights:
+            return o, wts
+        ctx.mark_non_differentiable()
+        return o, None
+
+    @staticmethod
+    def backward(ctx, do, dwts):
+        q, k, v, o, pt = ctx.saved_tensors
+        B, S, D = v.shape
+        H = D // 32
+        SP = pt.shape[-1]
+        do = _c(do)
+        dw = corr = None
+        if ctx.need_weights and dwts is not None:
+            dw = _c(dwts)
+            corr = _empty(v, B, H, S)
+        dst = torch.empty_like(pt)
+        if ctx.packed_qk:
+            dqk = _empty(v, B, S, 2 * D)
+            dq, dk, ldg_qk = dqk[:, :, :D], dqk[:, :, D:], 2 * D
+        else:
+            dq = _empty(v, B, S, D)
+            dk = _empty(v, B, S, D)
+            ldg_qk = D
+        dv = _empty(v, B, S, D)
+        L.call("stcat_mha_self_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
+               pt.data_ptr(), L._ptr(dw), L._ptr(corr), dst.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, ldg_qk, D, ctx.scale, L.stream_of(v))
+        if ctx.packed_qk:
+            return dqk, None, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None
+
+
+def mha_self(q, k, v, kpm, scale, need_weights=False):
+    return MhaSelfFn.apply(q, k, v, kpm, scale, need_weights, False)
+
+
+def mha_self_packed(qk, v, kpm, scale, need_weights=False):
+    """q = qk[..., :D], k = qk[..., D:] come from one packed projection; the gradient is
+    returned for the packed tensor directly."""
+    D = v.shape[-1]
+    return MhaSelfFn.apply(qk, qk[:, :, D:], v, kpm, scale, need_weights, True)
+
+
+class AttnQ1Fn(Function):
+    """Time-aligned cross-attention, one query per frame (query_decoder.py:386-417 with the custom MHA
+    of grounding_model/attention.py:184-393; query_decoder.py:618-639).
+    q1/q2: [B,256] (q2 optional second 32-wide part per head); k1/k2: [B,S,256]; v: [B,S,256]."""
+
+    @staticmethod
+    def forward(ctx, q1, q2, k1, k2, v, kpm, scale):
+        B, S, D = v.shape
+        H = D // 32
+        q1, q2, k1, k2, v = _c(q1), _c(q2), _c(k1), _c(k2), _c(v)
+        _chk(q1, q2, k1, k2, v)
+        kp = _c(kpm.to(torch.uint8)) if kpm is not None else None
+        out = _empty(v, B, D)
+        P = _empty(v, B, H, S)
+        L.call("stcat_attn_q1_fwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), L._ptr(kp),
+               out.data_ptr(), P.data_ptr(), B, H, S, D, D, D, scale, L.stream_of(v))
+        ctx.save_for_backward(q1, q2, k1, k2, v, P)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q1, q2, k1, k2, v, P = ctx.saved_tensors
+        B, S, D = v.shape
+        H = D // 32
+        g = _c(g)
+        dq1 = torch.empty_like(q1)
+        dq2 = torch.empty_like(q2) if q2 is not None else None
+        dk1 = torch.empty_like(k1)
+        dk2 = torch.empty_like(k2) if k2 is not None else None
+        dv = torch.empty_like(v)
+        L.call("stcat_attn_q1_bwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), P.data_ptr(),
+               g.data_ptr(), dq1.data_ptr(), L._ptr(dq2), dk1.data_ptr(), L._ptr(dk2), dv.data_ptr(), B, H, S, D, D, D,
+               ctx.scale, L.stream_of(v))
+        return dq1, dq2, dk1, dk2, dv, None, None
+
+
+def attn_q1(q1, q2, k1, k2, v, kpm, scale):
+    return AttnQ1Fn.apply(q1, q2, k1, k2, v, kpm, scale)
+
+
+# ------------------------------------------------------------------------------------
+# convolution building blocks (raw; composed by the backbone autograd function)
+# ------------------------------------------------------------------------------------
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv_fwd_raw(x, w_ohwi, scale, bias, res, stride, pad, relu):
+    n, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    y = _empty(x, n, OH, OW, Cout)
+    L.call("stcat_conv_fwd", x.data_ptr(), w_ohwi.data_ptr(), L._ptr(scale), L._ptr(bias), L._ptr(res), y.data_ptr(),
+           n, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), L.stream_of(x))
+    return y
+
+
+def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None):
+    n, H, W, Cin = in_shape
+    Cout, KH, KW, _ = w_ohwi.shape
+    dx = _empty(g, n, H, W, Cin) if out is None else out
+    L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), dx.data_ptr(), n, H, W, Cin, Cout, KH, KW,
+           stride, pad, L.stream_of(g))
+    return dx
+
+
+def conv_wgrad_raw(g, x, w_shape_ohwi, stride, pad):
+    n, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_shape_ohwi
+    dw = _zeros(g, Cout, KH, KW, Cin)
+    L.call("stcat_conv_wgrad", g.data_ptr(), x.data_ptr(), dw.data_ptr(), n, H, W, Cin, Cout, KH, KW, stride, pad,
+           L.stream_of(g))
+    return dw
+
+
+def stem_fwd_raw(frames, w_oihw, scale, bias):
+    n, _, H, W = frames.shape
+    OH, OW = conv_out_hw(H, W, 7, 2, 3)
+    y = _empty(frames, n, OH, OW, 64)
+    L.call("stcat_stem_fwd", frames.data_ptr(), w_oihw.data_ptr(), scale.data_ptr(), bias.data_ptr(), y.data_ptr(), n,
+           H, W, L.stream_of(frames))
+    return y
+
+
+def maxpool_raw(x):
+    n, H, W, C = x.shape
+    OH, OW = conv_out_hw(H, W, 3, 2, 1)
+    y = _empty(x, n, OH, OW, C)
+    L.call("stcat_maxpool3x3s2", x.data_ptr(), y.data_ptr(), n, H, W, C, L.stream_of(x))
+    return y
+
+
+def frozen_bn_fold(w, b, rm, rv, eps: float = 1e-5):
+    C = w.numel()
+    scale = torch.empty_like(w)
+    bias = torch.empty_like(w)
+    L.call("stcat_frozen_bn_fold", w.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), scale.data_ptr(),
+           bias.data_ptr(), C, eps, L.stream_of(w))
+    return scale, bias
+
+
+def temporal_map_argmax(pred_sted: torch.Tensor, durations: Sequence[int]) -> torch.Tensor:
+    """PostProcess's live 2D temporal map (post_processor.py:30-53): returns int32 [b,2] (start, end)."""
+    b, T, _ = pred_sted.shape
+    sted = _c(pred_sted.detach())
+    L.check_tensor(sted)
+    dur = torch.tensor(list(durations), dtype=torch.int32, device=sted.device)
+    out = torch.empty(b, 2, dtype=torch.int32, device=sted.device)
+    L.call("stcat_temporal_map_argmax", sted.data_ptr(), dur.data_ptr(), out.data_ptr(), b, T, L.stream_of(sted))
+    return out

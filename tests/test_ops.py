@@ -1,0 +1,343 @@
+"""Op-level parity of every C-ABI kernel against plain PyTorch fp32 CPU references.
+Each body runs twice: on the host emulator (CPU, `-m "not gpu"`) and on the real
+library (`-m gpu`).  Tolerances are fp32 round-off class (1e-4 relative to the
+tensor scale; the north-star bar is 1e-3)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from stcat_amd import _lib as L
+from stcat_amd import ops
+from tests.backends import both, close
+
+TOL = 2e-4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def _linear_case(dev, M, N, K, relu, res, tile=None):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    r = rnd(M, N, seed=4) if res else None
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    rr = r.clone().requires_grad_(True) if res else None
+    ref = F.linear(xr, wr, br)
+    if res:
+        ref = ref + rr
+    if relu:
+        ref = F.relu(ref)
+    gy = rnd(M, N, seed=5)
+    ref.backward(gy)
+    if tile:
+        L.call("stcat_debug_force_tile", *tile)
+    try:
+        xd, wd, bd = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+        rd = r.to(dev).requires_grad_(True) if res else None
+        y = ops.linear(xd, wd, bd, rd, relu)
+        y.backward(gy.to(dev))
+    finally:
+        L.call("stcat_debug_force_tile", 0, 0)
+    tag = f"linear M{M} N{N} K{K} tile{tile}"
+    close(y, ref, TOL, tag + " fwd")
+    close(xd.grad, xr.grad, TOL, tag + " dx")
+    close(wd.grad, wr.grad, TOL, tag + " dw")
+    close(bd.grad, br.grad, TOL, tag + " db")
+    if res:
+        close(rd.grad, rr.grad, TOL, tag + " dres")
+
+
+@both
+def _linear(dev, big):
+    _linear_case(dev, 70, 64, 64, relu=True, res=True)
+    _linear_case(dev, 130, 128, 128, relu=False, res=False, tile=(128, 128))
+    _linear_case(dev, 130, 128, 64, relu=True, res=True, tile=(128, 64))
+    _linear_case(dev, 65, 192, 64, relu=False, res=True, tile=(64, 64))
+    if big:
+        _linear_case(dev, 13248, 512, 256, relu=False, res=False)
+        _linear_case(dev, 13248, 2048, 256, relu=True, res=False)
+        _linear_case(dev, 13248, 256, 2048, relu=False, res=True)
+        _linear_case(dev, 64, 256, 512, relu=True, res=False)
+
+
+@both
+def _small_linear(dev, big):
+    for (M, N, K) in ((9, 4, 256), (7, 2, 256), (5, 1, 256)):
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+        xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        ref = F.linear(xr, wr, br)
+        gy = rnd(M, N, seed=5)
+        ref.backward(gy)
+        xd, wd, bd = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+        y = ops.linear(xd, wd, bd)
+        y.backward(gy.to(dev))
+        close(y, ref, TOL, f"small linear N{N}")
+        close(xd.grad, xr.grad, TOL, "dx")
+        close(wd.grad, wr.grad, TOL, "dw")
+        close(bd.grad, br.grad, TOL, "db")
+
+
+def _conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=None):
+    x = rnd(n, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    scale, bias = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    r = rnd(*ref.shape, seed=6) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    gy = rnd(*ref.shape, seed=5)
+    ref.backward(gy)
+    # NHWC / OHWI on the device
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(dev) if res else None
+    sd, bd = scale.to(dev), bias.to(dev)
+    if tile:
+        L.call("stcat_debug_force_tile", *tile)
+    try:
+        y = ops.conv_fwd_raw(xd, wd, sd, bd, rd, stride, pad, relu)
+        gyd = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+        G, dres = ops.act_bwd_raw(gyd, y, sd, want_g=True, want_res=True, relu=relu)
+        dx = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad)
+        dw = ops.conv_wgrad_raw(G, xd, wd.shape, stride, pad)
+        dx2 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, add=dx.clone())
+    finally:
+        L.call("stcat_debug_force_tile", 0, 0)
+    tag = f"conv {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
+    close(y.permute(0, 3, 1, 2), ref, TOL, tag + " fwd")
+    close(dx.permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
+    close(dx2.permute(0, 3, 1, 2), 2 * xr.grad, TOL, tag + " dgrad+add")
+    close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
+    if res:
+        mask = (ref > 0).float() if relu else torch.ones_like(ref)
+        close(dres.permute(0, 3, 1, 2), gy * mask, TOL, tag + " dres")
+
+
+@both
+def _conv(dev, big):
+    _conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True)
+    _conv_case(dev, 1, 8, 8, 64, 64, 3, 2, 1, relu=True, res=False)
+    _conv_case(dev, 1, 9, 7, 64, 128, 1, 2, 0, relu=False, res=False)
+    _conv_case(dev, 2, 5, 5, 128, 128, 1, 1, 0, relu=True, res=True, tile=(128, 128))
+    _conv_case(dev, 1, 12, 11, 128, 128, 3, 1, 1, relu=True, res=False, tile=(128, 64))
+    if big:
+        _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
+        _conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False)
+        _conv_case(dev, 4, 28, 28, 512, 1024, 1, 2, 0, relu=False, res=False)
+        _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True)
+        _conv_case(dev, 8, 56, 56, 256, 128, 1, 1, 0, relu=True, res=False)
+
+
+@both
+def _stem_pool(dev, big):
+    n, H = (2, 20) if not big else (4, 224)
+    x = rnd(n, 3, H, H, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5)
+    scale, bias = rnd(64, seed=3).abs() + 0.5, rnd(64, seed=4)
+    ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    y = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+    close(y.permute(0, 3, 1, 2), ref, TOL, "stem")
+    p = ops.maxpool_raw(y)
+    close(p.permute(0, 3, 1, 2), F.max_pool2d(ref, 3, 2, 1), TOL, "maxpool")
+    wb, bb, rm, rv = rnd(64, seed=7), rnd(64, seed=8), rnd(64, seed=9), rnd(64, seed=10).abs() + 0.1
+    s, b = ops.frozen_bn_fold(wb.to(dev), bb.to(dev), rm.to(dev), rv.to(dev))
+    sr = wb * (rv + 1e-5).rsqrt()
+    close(s, sr, 1e-6, "bn scale")
+    close(b, bb - rm * sr, 1e-6, "bn bias")
+
+
+@both
+def _layernorm(dev, big):
+    M = 37 if not big else 13248
+    x, r = rnd(M, 256, seed=1, scale=3.0), rnd(M, 256, seed=2)
+    g, b = rnd(256, seed=3) * 0.1 + 1, rnd(256, seed=4) * 0.1
+    xr, rr, gr, br = [t.clone().requires_grad_(True) for t in (x, r, g, b)]
+    ref = F.layer_norm(xr + rr, (256,), gr, br, 1e-5)
+    gy = rnd(M, 256, seed=5)
+    ref.backward(gy)
+    xd, rd, gd, bd = [t.to(dev).requires_grad_(True) for t in (x, r, g, b)]
+    y = ops.layer_norm(xd, gd, bd, res=rd)
+    y.backward(gy.to(dev))
+    close(y, ref, TOL, "ln fwd")
+    close(xd.grad, xr.grad, TOL, "ln dx")
+    close(rd.grad, rr.grad, TOL, "ln dres")
+    close(gd.grad, gr.grad, TOL, "ln dgamma")
+    close(bd.grad, br.grad, TOL, "ln dbeta")
+
+
+def _mha_ref(q, k, v, kpm, scale, H):
+    B, S, D = v.shape
+    hd = D // H
+    qh = (q * scale).view(B, S, H, hd).transpose(1, 2)
+    kh = k.view(B, S, H, hd).transpose(1, 2)
+    vh = v.view(B, S, H, hd).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2)
+    if kpm is not None:
+        sc = sc.masked_fill(kpm[:, None, None, :], float("-inf"))
+    p = sc.softmax(-1)
+    o = (p @ vh).transpose(1, 2).reshape(B, S, D)
+    return o, p.mean(1)
+
+
+def _mha_case(dev, B, S, H, need_w, packed, masked):
+    D = H * 32
+    qk = rnd(B, S, 2 * D, seed=1)
+    v = rnd(B, S, D, seed=2)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, S, dtype=torch.bool)
+        kpm[0, S - 3:] = True
+        if B > 1:
+            kpm[1, 1:4] = True
+    scale = 32 ** -0.5
+    qkr, vr = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    o_ref, w_ref = _mha_ref(qkr[..., :D], qkr[..., D:], vr, kpm, scale, H)
+    go, gw = rnd(B, S, D, seed=3), rnd(B, S, S, seed=4)
+    (o_ref * go).sum().backward(retain_graph=need_w)
+    if need_w:
+        (w_ref * gw).sum().backward()
+    qkd, vd = qk.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    kd = kpm.to(dev) if masked else None
+    if packed:
+        o, w = ops.mha_self_packed(qkd, vd, kd, scale, need_w)
+    else:
+        o, w = ops.mha_self(qkd[..., :D], qkd[..., D:], vd, kd, scale, need_w)
+    loss = (o * go.to(dev)).sum()
+    if need_w:
+        loss = loss + (w * gw.to(dev)).sum()
+    loss.backward()
+    tag = f"mha B{B} S{S} H{H} w{need_w} packed{packed}"
+    close(o, o_ref, TOL, tag + " out")
+    if need_w:
+        close(w, w_ref, TOL, tag + " weights")
+    close(qkd.grad, qkr.grad, TOL, tag + " dqk")
+    close(vd.grad, vr.grad, TOL, tag + " dv")
+
+
+@both
+def _mha_self(dev, big):
+    _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)
+    _mha_case(dev, 1, 8, 2, need_w=True, packed=True, masked=False)
+    _mha_case(dev, 1, 65, 1, need_w=True, packed=False, masked=True)
+    if big:
+        _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)
+        _mha_case(dev, 3, 237, 8, need_w=False, packed=True, masked=True)
+        _mha_case(dev, 1, 64, 8, need_w=True, packed=True, masked=False)
+        for S in (1, 32, 33, 96, 129, 180, 256):
+            _mha_case(dev, 2, S, 8, need_w=False, packed=True, masked=False)
+
+
+def _q1_case(dev, B, S, H, two):
+    D = H * 32
+    q1, q2 = rnd(B, D, seed=1), rnd(B, D, seed=2)
+    k1, k2, v = rnd(B, S, D, seed=3), rnd(B, S, D, seed=4), rnd(B, S, D, seed=5)
+    kpm = torch.zeros(B, S, dtype=torch.bool)
+    kpm[0, S // 2:] = True
+    scale = (64 if two else 32) ** -0.5
+    leaves = [t.clone().requires_grad_(True) for t in (q1, q2, k1, k2, v)]
+    a1, a2, b1, b2, vv = leaves
+    sc = (a1.view(B, 1, H, 32) * b1.view(B, S, H, 32)).sum(-1)
+    if two:
+        sc = sc + (a2.view(B, 1, H, 32) * b2.view(B, S, H, 32)).sum(-1)
+    sc = (sc * scale).masked_fill(kpm[:, :, None], float("-inf"))
+    p = sc.softmax(1)                                           # [B,S,H]
+    ref = (p[..., None] * vv.view(B, S, H, 32)).sum(1).reshape(B, D)
+    go = rnd(B, D, seed=6)
+    ref.backward(go)
+    dl = [t.to(dev).requires_grad_(True) for t in (q1, q2, k1, k2, v)]
+    out = ops.attn_q1(dl[0], dl[1] if two else None, dl[2], dl[3] if two else None, dl[4], kpm.to(dev), scale)
+    out.backward(go.to(dev))
+    tag = f"q1 B{B} S{S} two{two}"
+    close(out, ref, TOL, tag + " out")
+    for i, nm in enumerate(("dq1", "dq2", "dk1", "dk2", "dv")):
+        if not two and i in (1, 3):
+            continue
+        close(dl[i].grad, leaves[i].grad, TOL, tag + " " + nm)
+
+
+@both
+def _attn_q1(dev, big):
+    _q1_case(dev, 3, 11, 2, True)
+    _q1_case(dev, 5, 70, 1, False)
+    if big:
+        _q1_case(dev, 64, 206, 8, True)
+        _q1_case(dev, 64, 206, 8, False)
+        _q1_case(dev, 7, 256, 8, True)
+
+
+@both
+def _elementwise(dev, big):
+    a, b, c = rnd(6, 256, seed=1), rnd(6, 256, seed=2), rnd(6, 256, seed=3)
+    leaves = [t.clone().requires_grad_(True) for t in (a, b, c)]
+    dl = [t.to(dev).requires_grad_(True) for t in (a, b, c)]
+    row = rnd(256, seed=4)
+    ref = torch.tanh(torch.sigmoid(leaves[0] + leaves[1] + leaves[2]) * leaves[1] + row) + (leaves[0] + leaves[2])
+    out = ops.add(ops.tanh(ops.add_const(ops.mul(ops.sigmoid(ops.add3(*dl)), dl[1]), row.to(dev))),
+                  ops.add(dl[0], dl[2]))
+    g = rnd(6, 256, seed=5)
+    ref.backward(g)
+    out.backward(g.to(dev))
+    close(out, ref, TOL, "ew chain")
+    for i in range(3):
+        close(dl[i].grad, leaves[i].grad, TOL, f"ew grad {i}")
+    # inverse sigmoid incl. clamp edges, and its gradient
+    x = torch.tensor([-0.5, 0.0, 1e-4, 2e-3, 0.25, 0.5, 0.9, 0.9995, 1.0, 1.5] * 2).view(5, 4)
+    xr = x.clone().requires_grad_(True)
+    xc = xr.clamp(0, 1)
+    ref = torch.log(xc.clamp(min=1e-3) / (1 - xc).clamp(min=1e-3))
+    ref.sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.inverse_sigmoid(xd)
+    y.sum().backward()
+    close(y, ref, 1e-5, "invsig")
+    close(xd.grad, xr.grad, 1e-4, "invsig grad")
+    # FiLM rows
+    xx, gm, bt = rnd(7, 256, seed=6), rnd(256, seed=7), rnd(256, seed=8)
+    lr = [t.clone().requires_grad_(True) for t in (xx, gm, bt)]
+    ld = [t.to(dev).requires_grad_(True) for t in (xx, gm, bt)]
+    gg = rnd(7, 256, seed=9)
+    (lr[0] * lr[1] + lr[2]).backward(gg)
+    ops.affine_rows(*ld).backward(gg.to(dev))
+    for i in range(3):
+        close(ld[i].grad, lr[i].grad, TOL, f"affine grad {i}")
+
+
+@both
+def _sine_and_pos(dev, big):
+    from oracle import stcat_oracle as O
+    anchors = torch.rand(9, 1, 4, generator=torch.Generator().manual_seed(3))
+    ar = anchors.clone().requires_grad_(True)
+    ref = O.gen_sineembed(ar)
+    g = rnd(9, 1, 512, seed=1)
+    ref.backward(g)
+    ad = anchors.to(dev).requires_grad_(True)
+    y = ops.sine_embed(ad)
+    y.backward(g.to(dev))
+    close(y, ref, 1e-5, "sine embed")
+    close(ad.grad, ar.grad, 2e-4, "sine embed grad")
+    m = torch.zeros(2, 5, 7, dtype=torch.bool)
+    m[1, 3:, :] = True
+    m[1, :, 5:] = True
+    pos = ops.pos_sine_2d(m.to(dev))
+    refp = O.pos_sine_2d(m).flatten(2).permute(0, 2, 1)
+    close(pos, refp, 2e-5, "pos sine 2d")
+
+
+@both
+def _temporal_argmax(dev, big):
+    from oracle import stcat_oracle as O
+    for T, dur, seed in ((12, 12, 0), (12, 9, 1), (12, 6, 2), (64, 64, 3), (130, 100, 4), (5, 1, 5)):
+        sted = rnd(1, T, 2, seed=seed) * 2
+        if T == 12:
+            sted[0, 3, 0] = sted[0, :, 0].max() + 1
+            sted[0, 7, 1] = sted[0, :, 1].max() + 1
+            sted[0, 9, 1] = sted[0, 7, 1]  # exact tie: first max must win
+        boxes = torch.rand(T, 4)
+        _, _, flat = O.post_process(sted, boxes, torch.ones(T, 2), list(range(T)), dur)
+        got = ops.temporal_map_argmax(sted.to(dev), [dur]).cpu()
+        assert (int(got[0, 0]), int(got[0, 1])) == (flat // T, flat % T), (T, dur, got, flat)
