@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: videos/sec, forward + VideoSTGLoss + backward of the STCAT hot path
+(BASELINE.json metric; config C3 = VidSTG e2e_STCAT_R101: T=64, 448x448, d=256, 10 text tokens, one video per GPU).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  A step = forward, loss, backward of one synthetic video per rank, gradients
+averaged across ranks (RCCL all-reduce overlapped with backward) and usable at the end of the step; inputs
+are resident in HBM before the timed region.  Weights are the deterministic synthetic set (no checkpoints
+offline); arithmetic is fp32 on v_mfma_f32_32x32x2_f32 — the mode that meets the 1e-3 parity bar.
+`roofline` is measured live with HIP events (torch.cuda.Event on the launch stream) around every C-ABI
+launch in one extra instrumented step after the timed region; `cpu_baseline` times the CPU oracle
+(a port of the reference path) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stcat_amd import _lib, synth  # noqa: E402
+from stcat_amd.dist import GradBucketReducer  # noqa: E402
+from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
+from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
+
+PEAK_TFLOPS_F32_MFMA = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic FLOPs of one C-ABI launch (2*MAC of the contraction it performs), from its arguments
+# ------------------------------------------------------------------------------------------------
+def _flops(name, a):
+    if name == "stcat_conv_fwd":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[6:15]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        return 2.0 * n * OH * OW * Cout * KH * KW * Cin
+    if name == "stcat_conv_dgrad":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[4:13]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        return 2.0 * n * OH * OW * Cout * KH * KW * Cin  # algorithmic MACs of the transposed conv
+    if name == "stcat_conv_wgrad":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[3:12]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        return 2.0 * n * OH * OW * Cout * KH * KW * Cin
+    if name == "stcat_stem_fwd":
+        n, H, W = a[5:8]
+        return 2.0 * n * (H // 2) * (W // 2) * 64 * 147
+    if name == "stcat_linear_fwd":
+        return 2.0 * a[5] * a[6] * a[7]
+    if name in ("stcat_linear_dgrad", "stcat_linear_wgrad"):
+        o = 4 if name == "stcat_linear_dgrad" else 3
+        return 2.0 * a[o] * a[o + 1] * a[o + 2]
+    if name == "stcat_mha_self_fwd":
+        B, H, S = a[6:9]
+        return 2.0 * 2 * B * H * S * S * 32
+    if name == "stcat_mha_self_bwd":
+        B, H, S = a[12:15]
+        return 2.0 * 4 * B * H * S * S * 32
+    return 0.0
+
+
+class LaunchProfiler:
+    """Wraps _lib.call with a pair of HIP events per launch (same stream as the launch)."""
+
+    def __init__(self):
+        self.records = []
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = _lib.call
+
+        def timed(name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(name, *args)
+            e1.record()
+            self.records.append((name, _flops(name, args), e0, e1))
+
+        _lib.call = timed
+        import stcat_amd.ops as ops_mod
+        ops_mod.L.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call = self._orig
+        torch.cuda.synchronize()
+
+    def summary(self):
+        agg = {}
+        for name, fl, e0, e1 in self.records:
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flop"] += fl
+        return agg
+
+
+def cpu_baseline(T_sample: int, res: int, L: int, T_full: int, threads: int):
+    """The oracle (CPU port of the reference path) on a bounded sample: T_sample frames at full resolution,
+    forward + loss + backward, scaled to one T_full-frame video (cost is linear in frames: the per-frame
+    backbone is 93% of the work and attention is per frame)."""
+    from oracle import stcat_oracle as O
+    torch.set_num_threads(threads)
+    sd = synth.synth_state_dict()
+    frozen = ("vis_encoder.0.body.conv1", "vis_encoder.0.body.bn1", "vis_encoder.0.body.layer1")
+    for k, v in sd.items():
+        v.requires_grad_(not (k.startswith(frozen) or ".bn" in k or "downsample.1" in k or k.endswith(".te")))
+    frames = synth.synth_frames(T_sample, res)
+    mask = torch.zeros(T_sample, res, res, dtype=torch.bool)
+    act, tb = synth.synth_targets(T_sample)
+    text = synth.synth_text(L)
+    t0 = time.perf_counter()
+    out = O.stcat_forward(sd, frames, mask, text)
+    O.total_loss(O.criterion(out, act, tb)).backward()
+    dt = time.perf_counter() - t0
+    return {"value": (T_sample / T_full) / dt, "unit": "videos/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd on T={T_sample} of {T_full} frames at {res}x{res} ({dt:.1f} s), "
+                      f"scaled by {T_sample}/{T_full}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3", choices=list(synth.CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=8)
+    ap.add_argument("--roberta-dummy", action="store_true",
+                    help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    _lib.load()
+
+    T, res, L = synth.CONFIGS[args.config]
+    model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
+    model.eval()  # dropout off (parity mode); gradients flow
+    synth.fill_module_(model)
+    model.to(dev)
+    reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0)
+
+    frames = synth.synth_frames(T, res, seed=1000 * 3 + rank).to(dev)
+    mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+    videos = NestedTensor(frames, mask, [T])
+    act, tb = synth.synth_targets(T, seed=rank)
+    targets = [{"actioness": act.to(dev), "boxs": BoxList(tb).to(dev)}]
+
+    def step():
+        reducer.zero_grad()
+        out = model(videos, ["synthetic"])
+        losses = criterion(out, targets, [T])
+        total = sum(losses[k] * wd[k] for k in losses)
+        total.backward()
+        reducer.finish()
+        return total
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    elapsed = dt.item()
+
+    roof, kernels = None, None
+    if rank == 0 and not args.no_profile:
+        with LaunchProfiler() as prof:
+            step()
+        agg = prof.summary()
+        kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                       "tflops": (round(v["flop"] / v["ms"] / 1e9, 2) if v["flop"] and v["ms"] else None)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        dom = max((k for k in agg if agg[k]["flop"] > 0), key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        ach = d["flop"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F32_MFMA,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F32_MFMA, 4), "traffic": None,
+                "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
+        mm = sum(v["flop"] for v in agg.values())
+        mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)
+        roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
+                                    "gflop_per_step": round(mm / 1e9, 1)}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, os.cpu_count() or 1)
+
+    if rank == 0:
+        line = {
+            "metric": "videos/sec fwd+bwd @ T=64 res=448 d=256", "value": round(world * args.steps / elapsed, 4),
+            "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
+                                   "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
+                       "allreduce_bytes": reducer.message_bytes},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

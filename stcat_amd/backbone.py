@@ -1,0 +1,241 @@
+"""ResNet-101 + FrozenBatchNorm2d visual encoder on the HIP implicit-GEMM kernels.
+
+Drop-in for the reference factory ``models.vision_model.build_vis_encoder`` (vision_model/__init__.py:5-24):
+same module tree / state-dict keys (``0.body.conv1.weight`` ... ``0.body.layer4.2.bn3.running_var``), same
+``forward(NestedTensor) -> (NestedTensor, pos)`` contract (backbone.py:93-102, 151-159), ``num_channels``.
+The arithmetic — torchvision's ResNet-101 v1.5 topology, not part of the reference repository — runs as
+one autograd function over NHWC activations: conv + FrozenBN + residual + ReLU are one kernel each,
+weights live as [O,I,KH,KW] parameters in channels_last memory (physically OHWI, what the kernels read).
+Stem and layer1 are frozen as in BackboneBase (backbone.py:78-85): they have no backward at all.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import ops
+from .misc import NestedTensor
+
+BLOCKS = (3, 4, 23, 3)
+PLANES = (64, 128, 256, 512)
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Buffers only (weight, bias, running_mean, running_var): backbone.py:16-66.  The affine form
+    x*scale + bias is applied inside the conv epilogue; ``folded()`` caches scale/bias per buffer version."""
+
+    def __init__(self, n: int):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self._cache = None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)  # backbone.py:42-44
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def folded(self):
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((b.data_ptr(), b._version) for b in bufs)
+        if self._cache is None or self._cache[0] != key:
+            self._cache = (key, ops.frozen_bn_fold(*bufs, eps=1e-5))
+        return self._cache[1]
+
+
+def _conv(cin, cout, k, stride=1, pad=0):
+    m = nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False)  # parameter container only
+    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return m
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = _conv(inplanes, planes, 1)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = _conv(planes, planes, 3, stride, 1)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = _conv(planes, planes * 4, 1)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet101Body(nn.Module):
+    """Children named as torchvision's resnet101 up to layer4 (IntermediateLayerGetter, backbone.py:90)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        inplanes = 64
+        for li, (nblk, planes) in enumerate(zip(BLOCKS, PLANES), start=1):
+            blocks = []
+            for bi in range(nblk):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                ds = None
+                if bi == 0:
+                    ds = nn.Sequential(_conv(inplanes, planes * 4, 1, stride), FrozenBatchNorm2d(planes * 4))
+                blocks.append(Bottleneck(inplanes, planes, stride, ds))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+    def blocks(self):
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}"):
+                yield li, blk
+
+
+def _ohwi(w: torch.Tensor) -> torch.Tensor:
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class _BackboneFn(Function):
+    """frames [n,3,H,W] (NCHW, as handed over by the data pipeline) -> layer4 features NHWC [n,H/32,W/32,2048]."""
+
+    @staticmethod
+    def forward(ctx, frames, body: ResNet101Body, *weights):
+        need_bwd = any(w.requires_grad for w in weights)
+        s, b = body.bn1.folded()
+        x = ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+        x = ops.maxpool_raw(x)
+        tape = []
+        for li, blk in body.blocks():
+            w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
+            s1, b1 = blk.bn1.folded()
+            s2, b2 = blk.bn2.folded()
+            s3, b3 = blk.bn3.folded()
+            o1 = ops.conv_fwd_raw(x, w1, s1, b1, None, 1, 0, True)
+            o2 = ops.conv_fwd_raw(o1, w2, s2, b2, None, blk.stride, 1, True)
+            wd = sd = None
+            if blk.downsample is not None:
+                wd = _ohwi(blk.downsample[0].weight)
+                sd, bd = blk.downsample[1].folded()
+                idt = ops.conv_fwd_raw(x, wd, sd, bd, None, blk.stride, 0, False)
+            else:
+                idt = x
+            y = ops.conv_fwd_raw(o2, w3, s3, b3, idt, 1, 0, True)
+            trainable = blk.conv1.weight.requires_grad
+            if need_bwd and trainable:
+                tape.append((blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
+            x = y
+        ctx.tape = tape
+        ctx.body = body
+        ctx.first_trainable = tape[0][0] if tape else None
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = {}
+        dy = dy.contiguous()
+        for (blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd)) in reversed(ctx.tape):
+            need_dx = blk is not ctx.first_trainable  # below the first trainable block everything is frozen
+            g3, didt = ops.act_bwd_raw(dy, y, s3, want_g=True, want_res=need_dx, relu=True)
+            grads[id(blk.conv3.weight)] = ops.conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
+            do2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0)
+            g2, _ = ops.act_bwd_raw(do2, o2, s2, want_g=True, relu=True)
+            grads[id(blk.conv2.weight)] = ops.conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
+            do1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1)
+            g1, _ = ops.act_bwd_raw(do1, o1, s1, want_g=True, relu=True)
+            grads[id(blk.conv1.weight)] = ops.conv_wgrad_raw(g1, x, w1.shape, 1, 0)
+            gd = None
+            if wd is not None:
+                gd, _ = ops.act_bwd_raw(dy, y, sd, want_g=True, relu=True)  # dz * scale_ds
+                grads[id(blk.downsample[0].weight)] = ops.conv_wgrad_raw(gd, x, wd.shape, blk.stride, 0)
+            if not need_dx:
+                break
+            if wd is not None:
+                dx = ops.conv_dgrad_raw(gd, wd, x.shape, blk.stride, 0)
+                dx = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dx, out=dx)
+            else:
+                dx = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=didt)
+            dy = dx
+        out = []
+        for w in ctx.body.parameters():  # same order as the *weights passed to forward
+            g = grads.get(id(w))
+            out.append(g.permute(0, 3, 1, 2) if g is not None else None)  # OHWI buffer seen as [O,I,KH,KW]
+        ctx.tape = None
+        return (None, None, *out)
+
+
+class Backbone(nn.Module):
+    """BackboneBase + Backbone (backbone.py:69-121): ``body`` holds the ResNet, layer2-4 are trainable."""
+
+    def __init__(self, name: str = "resnet101", train_backbone: bool = True, return_interm_layers: bool = False,
+                 dilation: bool = False):
+        super().__init__()
+        if name != "resnet101" or dilation or return_interm_layers:
+            raise ValueError("stcat_amd implements the resnet101 / no-dilation / layer4-only configuration "
+                             "selected by both reference experiment files")
+        self.body = ResNet101Body()
+        for n_, p in self.body.named_parameters():
+            if not train_backbone or ("layer2" not in n_ and "layer3" not in n_ and "layer4" not in n_):
+                p.requires_grad_(False)
+        self.num_channels = 2048
+
+    def features_nhwc(self, frames: torch.Tensor) -> torch.Tensor:
+        weights = [p for p in self.body.parameters()]
+        return _BackboneFn.apply(frames, self.body, *weights)
+
+    def forward(self, tensor_list: NestedTensor):
+        feat = self.features_nhwc(tensor_list.tensors)
+        m = tensor_list.mask
+        assert m is not None
+        mask = F.interpolate(m[None].float(), size=feat.shape[1:3]).to(torch.bool)[0]  # backbone.py:100
+        return {"0": NestedTensor(feat.permute(0, 3, 1, 2), mask, tensor_list.durations)}
+
+
+class PositionEmbeddingSine(nn.Module):
+    """vision_model/position_encoding.py:51-94 with num_pos_feats=128, normalize=True (built at :138)."""
+
+    def __init__(self, num_pos_feats: int = 128, temperature: int = 10000, normalize: bool = True, scale=None):
+        super().__init__()
+        if num_pos_feats != 128 or temperature != 10000 or not normalize:
+            raise ValueError("only PositionEmbeddingSine(128, normalize=True) is implemented")
+
+    def tokens(self, mask: torch.Tensor) -> torch.Tensor:
+        return ops.pos_sine_2d(mask)  # [n, h*w, 256]
+
+    def forward(self, tensor_list: NestedTensor) -> torch.Tensor:
+        n, h, w = tensor_list.mask.shape
+        return self.tokens(tensor_list.mask).view(n, h, w, 256).permute(0, 3, 1, 2)
+
+
+class Joiner(nn.Sequential):
+    """backbone.py:147-159."""
+
+    def __init__(self, backbone: Backbone, position_embedding: PositionEmbeddingSine):
+        super().__init__(backbone, position_embedding)
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        out = self[0](tensor_list)["0"]
+        return out, self[1](out).to(out.tensors.dtype)
+
+    def forward_tokens(self, frames: torch.Tensor, mask: torch.Tensor):
+        """internal fast path: NHWC features, layer4-resolution mask, token-major positions."""
+        feat = self[0].features_nhwc(frames)
+        m = F.interpolate(mask[None].float(), size=feat.shape[1:3]).to(torch.bool)[0]
+        return feat, m, self[1].tokens(m)
+
+
+def build_vis_encoder(cfg=None) -> Joiner:
+    """Counterpart of models/vision_model/__init__.py:5-24."""
+    train_backbone, name, dilation, pos_enc = True, "resnet101", False, "sine"
+    if cfg is not None:
+        train_backbone = cfg.SOLVER.VIS_BACKBONE_LR > 0
+        name = cfg.MODEL.VISION_BACKBONE.NAME
+        dilation = cfg.MODEL.VISION_BACKBONE.DILATION
+        pos_enc = cfg.MODEL.VISION_BACKBONE.POS_ENC
+        if cfg.MODEL.STCAT.HIDDEN != 256:
+            raise ValueError("HIDDEN must be 256")
+    if pos_enc != "sine":
+        raise ValueError(f"not supported {pos_enc}")  # position_encoding.py:144
+    return Joiner(Backbone(name, train_backbone, False, dilation), PositionEmbeddingSine(128, normalize=True))

@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange: one video per GPU, one process per GPU (scripts/train_net.py:31-36 wraps
+the reference model in torch DDP with find_unused_parameters=True).  Here instead:
+
+* every trainable, *live* parameter's ``.grad`` is a view into a few large flat fp32 buckets laid out in
+  backward-readiness order (heads -> decoders -> encoder -> input_proj -> layer4 -> layer2), so autograd
+  accumulates straight into the communication buffers;
+* the 14 parameter tensors that never receive a gradient in the reference (ground_encoder.fusion.*,
+  decoder.layers.*.ca_qtime_proj.*) are excluded statically instead of being discovered
+  by a graph walk every step;
+* when the last gradient of a bucket has been accumulated its all-reduce is launched asynchronously —
+  RCCL runs it on its own stream while the (much longer) backbone backward keeps the compute stream busy;
+* ``finish()`` waits for the collectives and applies the 1/world mean.
+
+xGMI is point-to-point (7 links per GPU): few large messages beat many small ones, hence big buckets.
+``torch.distributed`` backend "nccl" is RCCL on ROCm; the CPU test-suite drives the same class over gloo.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+DEAD_PARAM_MARKERS = ("ground_encoder.fusion.", ".ca_qtime_proj.")
+
+
+def live_trainable(named_params):
+    return [(n, p) for n, p in named_params if p.requires_grad and not any(m in n for m in DEAD_PARAM_MARKERS)]
+
+
+class GradBucketReducer:
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 128.0, process_group=None, extra_numel: int = 0):
+        """extra_numel: a dummy tail bucket (e.g. 124.6 M elements to emulate the reference's RoBERTa gradients
+        in the message size) — reduced with the rest, never read."""
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = live_trainable(model.named_parameters())[::-1]  # reverse registration ~ readiness order
+        cap = int(bucket_mb * (1 << 20) // 4)
+        self.buckets: List[Dict] = []
+        cur, cur_n = [], 0
+        for n, p in params:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append({"params": cur, "numel": cur_n})
+                cur, cur_n = [], 0
+            cur.append((n, p))
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append({"params": cur, "numel": cur_n})
+        self._owner = {}
+        for bi, b in enumerate(self.buckets):
+            dev = b["params"][0][1].device
+            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev)
+            off = 0
+            for n, p in b["params"]:
+                view = b["flat"][off:off + p.numel()]
+                # keep the parameter's memory format (conv weights are channels_last)
+                g = torch.as_strided(view, p.shape, p.stride()) if p.is_contiguous(memory_format=torch.channels_last) \
+                    and p.dim() == 4 and not p.is_contiguous() else view.view(p.shape)
+                p.grad = g
+                off += p.numel()
+                self._owner[p] = bi
+                p.register_post_accumulate_grad_hook(self._on_grad)
+            b["pending"] = len(b["params"])
+            b["work"] = None
+        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=self.buckets[0]["flat"].device) \
+            if extra_numel else None
+        self._extra_work = None
+
+    # ---- per step -------------------------------------------------------------------------------
+    def zero_grad(self):
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            b["work"] = None
+
+    def _launch(self, b):
+        if self.world > 1:
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b["pending"] = -1
+
+    def _on_grad(self, p):
+        b = self.buckets[self._owner[p]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Block the current stream until every bucket is reduced, then average."""
+        if self.extra is not None and self.world > 1:
+            self._extra_work = dist.all_reduce(self.extra, group=self.group, async_op=True)
+        for b in self.buckets:
+            if b["pending"] >= 0:  # a parameter got no gradient this step: reduce what is there
+                self._launch(b)
+        if self.world > 1:
+            for b in self.buckets:
+                b["work"].wait()
+                b["flat"].mul_(1.0 / self.world)
+            if self._extra_work is not None:
+                self._extra_work.wait()
+
+    @property
+    def message_bytes(self) -> int:
+        return 4 * (sum(b["numel"] for b in self.buckets) + (self.extra.numel() if self.extra is not None else 0))
