@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(synth.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=8)
+    ap.add_argument("--cpu-sample-frames", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
     ap.add_argument("--roberta-dummy", action="store_true",
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
     args = ap.parse_args()
@@ -216,7 +217,7 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, os.cpu_count() or 1)
+        cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, min(os.cpu_count() or 1, args.cpu_threads))
 
     if rank == 0:
         line = {

@@ -73,6 +73,24 @@ static __device__ __forceinline__ long stcat_gather_pix(const IgemmGeom& g, int 
     }                                                                                      \
   }
 
+// Two-level accumulation: the MFMA accumulates one sequential fp32 chain per output; over K up to 4608
+// that costs ~sqrt(K) ulps.  Every 8 K-tiles (128 terms) the running tile is folded into `tot`, which
+// brings round-off to the level of a blocked CPU sum at the price of 16*TM*TN more VGPRs.
+#define STCAT_ACC_FLUSH(KT)                                              \
+  if ((((KT) & 7) == 7) || (KT) == nk - 1) {                             \
+    STCAT_UNROLL                                                         \
+    for (int i_ = 0; i_ < TM; ++i_) {                                    \
+      STCAT_UNROLL                                                       \
+      for (int j_ = 0; j_ < TN; ++j_) {                                  \
+        STCAT_UNROLL                                                     \
+        for (int r_ = 0; r_ < 16; ++r_) {                                \
+          tot[i_][j_][r_] += acc[i_][j_][r_];                            \
+          acc[i_][j_][r_] = 0.f;                                         \
+        }                                                                \
+      }                                                                  \
+    }                                                                    \
+  }
+
 // ---------------------------------------------------------------------------------
 // forward: C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (kh, kw, ci), ci fastest
 // ---------------------------------------------------------------------------------
@@ -110,13 +128,13 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(IgemmParams p) {
   STCAT_UNROLL
   for (int j = 0; j < TN; ++j) brow[j] = p.B + (long)(n0 + (t >> 2) + 64 * j) * p.ldb + r4;
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TN], tot[TM][TN];
   STCAT_UNROLL
   for (int i = 0; i < TM; ++i) {
     STCAT_UNROLL
     for (int j = 0; j < TN; ++j) {
       STCAT_UNROLL
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
     }
   }
 
@@ -154,6 +172,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(IgemmParams p) {
     const int buf = kt & 1;
     if (kt + 1 < nk) STCAT_FWD_LOAD(kt + 1)
     STCAT_IGEMM_COMPUTE(As[buf], Bs[buf])
+    STCAT_ACC_FLUSH(kt)
     if (kt + 1 < nk) STCAT_FWD_STORE(buf ^ 1)
     __syncthreads();
   }
@@ -172,7 +191,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m < p.M) {
-          float val = acc[tm][tn][r] * sc + bi;
+          float val = tot[tm][tn][r] * sc + bi;
           if (p.res) val += p.res[(long)m * p.ldr + n];
           if (p.relu) val = fmaxf(val, 0.f);
           const long row = (long)(m / p.c_group) * p.c_group_stride + (long)(m % p.c_group) * p.ldc;
@@ -219,13 +238,13 @@ __global__ void __launch_bounds__(256) igemm_dgrad_kernel(IgemmParams p) {
       a_bw[j] = 0;
     }
   }
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TN], tot[TM][TN];
   STCAT_UNROLL
   for (int i = 0; i < TM; ++i) {
     STCAT_UNROLL
     for (int j = 0; j < TN; ++j) {
       STCAT_UNROLL
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
     }
   }
   float4 ra[TM], rb[BJ];
@@ -265,6 +284,7 @@ __global__ void __launch_bounds__(256) igemm_dgrad_kernel(IgemmParams p) {
     const int buf = kt & 1;
     if (kt + 1 < nk) STCAT_DG_LOAD(kt + 1)
     STCAT_IGEMM_COMPUTE(As[buf], Bs[buf])
+    STCAT_ACC_FLUSH(kt)
     if (kt + 1 < nk) STCAT_DG_STORE(buf ^ 1)
     __syncthreads();
   }
@@ -280,7 +300,7 @@ __global__ void __launch_bounds__(256) igemm_dgrad_kernel(IgemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (m < p.M) {
-          float val = acc[tm][tn][r];
+          float val = tot[tm][tn][r];
           if (p.res) val += p.res[(long)m * p.ldr + n];  // fused gradient accumulation
           p.C[(long)m * p.ldc + n] = val;
         }

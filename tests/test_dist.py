@@ -1,0 +1,104 @@
+"""Data-parallel gradient exchange (stcat_amd/dist.py) over gloo, world_size 2, on CPU.
+No kernels involved: this covers the bucket layout, the readiness hooks, asynchronous launch,
+averaging, the statically excluded dead parameters and the dummy (RoBERTa-sized) tail bucket."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from stcat_amd.dist import GradBucketReducer, live_trainable
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(8, 16, 3, bias=False)
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+        self.lin = nn.Linear(16, 4)
+        self.ground_encoder = nn.Module()
+        self.ground_encoder.fusion = nn.Linear(4, 4)  # dead in the reference: must stay out of the buckets
+        self.frozen = nn.Linear(4, 4)
+        for p in self.frozen.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, x):
+        return self.lin(self.conv(x).mean((2, 3)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Toy()
+    red = GradBucketReducer(model, bucket_mb=0.002, extra_numel=100)  # ~2 KB buckets -> several buckets
+    assert len(red.buckets) >= 2
+    names = [n for b in red.buckets for n, _ in b["params"]]
+    assert not any("fusion" in n or "frozen" in n for n in names)
+    res = []
+    for step in range(2):  # second step checks re-arming of the hooks / zeroing
+        red.zero_grad()
+        x = torch.full((2, 8, 5, 5), float(rank + 1 + step))
+        model(x).square().sum().backward()
+        red.finish()
+        res.append({n: p.grad.clone().numpy() for n, p in live_trainable(model.named_parameters())})
+        assert model.conv.weight.grad.stride() == model.conv.weight.stride()  # channels_last view kept
+    q.put((rank, res, red.message_bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(step):
+    torch.manual_seed(0)
+    model = Toy()
+    grads = []
+    for rank in range(2):
+        model.zero_grad()
+        x = torch.full((2, 8, 5, 5), float(rank + 1 + step))
+        model(x).square().sum().backward()
+        grads.append({n: p.grad.clone() for n, p in live_trainable(model.named_parameters())})
+    return {n: (grads[0][n] + grads[1][n]) / 2 for n in grads[0]}
+
+
+def test_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    for step in range(2):
+        want = _single(step)
+        for rank, res, nbytes in out:
+            for n, g in res[step].items():
+                assert torch.allclose(torch.from_numpy(g), want[n], rtol=1e-5, atol=1e-6), (rank, step, n)
+    assert out[0][2] == out[1][2] and out[0][2] > 400
+
+
+def test_reducer_single_process_is_identity():
+    model = Toy()
+    red = GradBucketReducer(model)
+    red.zero_grad()
+    model(torch.ones(1, 8, 5, 5)).sum().backward()
+    red.finish()
+    ref = Toy()
+    ref.load_state_dict(model.state_dict())
+    ref(torch.ones(1, 8, 5, 5)).sum().backward()
+    for (n, p), (_, q) in zip(live_trainable(model.named_parameters()), live_trainable(ref.named_parameters())):
+        assert torch.allclose(p.grad, q.grad), n
