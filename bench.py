@@ -32,6 +32,7 @@ from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
 from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
 
 PEAK_TFLOPS_F32_MFMA = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_TFLOPS_BF16_MFMA = 2500.0  # dense bf16 MFMA peak; a split-bf16 xN product costs N bf16 MFMA flops per flop
 PEAK_HBM_GBS = 8000.0
 
 
@@ -137,6 +138,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
+    ap.add_argument("--mma", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+                    help="arithmetic of the conv/Linear GEMM family (fp32 in/out in every mode)")
     ap.add_argument("--roberta-dummy", action="store_true",
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
     args = ap.parse_args()
@@ -153,6 +156,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     _lib.load()
+    _lib.set_mma_mode(args.mma)
 
     T, res, L = synth.CONFIGS[args.config]
     model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
@@ -204,8 +208,12 @@ def main():
         dom = max((k for k in agg if agg[k]["flop"] > 0), key=lambda k: agg[k]["ms"])
         d = agg[dom]
         ach = d["flop"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F32_MFMA,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F32_MFMA, 4), "traffic": None,
+        # roofline in ISSUED matrix flops: algorithmic flops x (1 | 3 | 6) against the pipe that executes them
+        mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6}[args.mma]
+        peak = PEAK_TFLOPS_F32_MFMA if args.mma == "f32" else PEAK_TFLOPS_BF16_MFMA
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach * mult, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach * mult / peak, 4), "traffic": None,
+                "algorithmic_tflops": round(ach, 2), "mfma_flops_per_algorithmic_flop": mult,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
         mm = sum(v["flop"] for v in agg.values())
@@ -224,7 +232,9 @@ def main():
             "metric": "videos/sec fwd+bwd @ T=64 res=448 d=256", "value": round(world * args.steps / elapsed, 4),
             "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 x3 (fp32 accumulate)",
+                      "bf16x6": "f32 via split-bf16 x6 (fp32 accumulate)"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "allreduce_bytes": reducer.message_bytes},

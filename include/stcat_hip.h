@@ -25,6 +25,12 @@ extern "C" {
 
 int stcat_version(void);
 const char* stcat_last_error(void);
+/* arithmetic of the implicit-GEMM family (conv / Linear fwd, dgrad, wgrad); inputs and outputs stay fp32:
+ *   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products)
+ *   2 = split-bf16 x3: x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate
+ *   3 = split-bf16 x6: three bf16 pieces, six cross terms (fp32-class products) */
+int stcat_set_mma_mode(int mode);
+int stcat_get_mma_mode(void);
 /* tuning/test hook: force the implicit-GEMM block tile (128x128, 128x64, 64x64; 0,0 = heuristic) */
 int stcat_debug_force_tile(int bm, int bn);
 

@@ -45,6 +45,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiifs",
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_debug_force_tile": "ii",
+    "stcat_set_mma_mode": "i",
+    "stcat_get_mma_mode": "",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
 
@@ -89,6 +91,20 @@ def _use_library_for_testing(path: str) -> None:
 
 def backend() -> str:
     return _backend
+
+
+MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+
+
+def set_mma_mode(mode: str) -> None:
+    """Arithmetic of the conv / Linear GEMM family: 'f32' (exact fp32 MFMA), 'bf16x3' or 'bf16x6'
+    (fp32 operands split into bf16 pieces on the bf16 matrix pipe, fp32 accumulate)."""
+    call("stcat_set_mma_mode", MMA_MODES[mode])
+
+
+def get_mma_mode() -> str:
+    code = load().stcat_get_mma_mode()
+    return {v: k for k, v in MMA_MODES.items()}[code]
 
 
 def _ptr(t):

@@ -38,6 +38,7 @@ struct IgemmParams {
   int c_group, c_group_stride;  // output row m -> (m / c_group) * c_group_stride + (m % c_group) * ldc
   int relu;
   int k_chunk;  // wgrad: rows of the M reduction per grid.z slice (multiple of 16)
+  unsigned a_bytes, b_bytes;  // extents of A and B for the bounds-checked buffer loads (split-bf16 kernels)
   IgemmGeom g;
 };
 
@@ -194,7 +195,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(IgemmParams p) {
           float val = tot[tm][tn][r] * sc + bi;
           if (p.res) val += p.res[(long)m * p.ldr + n];
           if (p.relu) val = fmaxf(val, 0.f);
-          const long row = (long)(m / p.c_group) * p.c_group_stride + (long)(m % p.c_group) * p.ldc;
+          const long row = p.c_group >= p.M ? (long)m * p.ldc
+                                            : (long)(m / p.c_group) * p.c_group_stride + (long)(m % p.c_group) * p.ldc;
           p.C[row + n] = val;
         }
       }

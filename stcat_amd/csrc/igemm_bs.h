@@ -1,0 +1,351 @@
+// Split-bf16 implicit GEMM on v_mfma_f32_32x32x16_bf16 (2.5 PF dense pipe on gfx950).
+//
+// Same contractions, geometry and epilogues as igemm.h, but every fp32 operand value x is split while it is
+// staged into LDS:  x = p0 + p1 (+ p2),  p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1),
+// and the product a*b is accumulated in fp32 from the significant cross terms:
+//     NS = 2 ("bf16x3"):  a0*b0 + a0*b1 + a1*b0                      (~2^-16 relative per product)
+//     NS = 3 ("bf16x6"):  + a0*b2 + a1*b1 + a2*b0                    (~2^-24: fp32-class)
+// 3 (6) MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles per 16 reduction terms: 5.3x (2.7x) less matrix
+// pipe time at fp32-input / fp32-output semantics.  Activations and weights stay fp32 in HBM.
+//
+// Tiling: 256 threads = 2x2 waves, BMxBN block tile, K step 32.  LDS holds one plane per split piece,
+// rows of 32 bf16 padded to 40 (80 B): an MFMA fragment is one 16-byte ds_read_b128 per lane and the 80-byte
+// row stride is conflict-free for its 16-lane groups.  Two staging paths:
+//   R : operand rows are contiguous along the reduction (NHWC pixels x channels, weights [N][K]) —
+//       float4 -> split -> one ds_write_b64 per plane;
+//   O : operand is reduction-major (dY^T / X^T in wgrad, W in dgrad) — each thread loads a 4(k) x 4(rows)
+//       block with four coalesced float4 loads, transposes it in registers, then ds_write_b64 per row.
+// Double-buffered LDS, next tile prefetched into registers during the MFMA phase, one barrier per K step.
+#pragma once
+#include "igemm.h"
+
+#define STCAT_BS_LDK 40  // bf16 elements per LDS row (32 + 8 pad)
+
+template <int NS>
+static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int plane_elems, float x0, float x1, float x2,
+                                                           float x3) {
+  float r[4] = {x0, x1, x2, x3};
+  STCAT_UNROLL
+  for (int s = 0; s < NS; ++s) {
+    bf16x4 pk;
+    STCAT_UNROLL
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h = (__bf16)r[e];
+      pk[e] = h;
+      r[e] -= (float)h;
+    }
+    *reinterpret_cast<bf16x4*>(dst + s * plane_elems) = pk;
+  }
+}
+
+// all MFMAs of one 16-wide k-step for a TMxTN wave tile
+#define STCAT_BS_COMPUTE(AS, BS)                                                                        \
+  STCAT_UNROLL                                                                                          \
+  for (int ks = 0; ks < 2; ++ks) {                                                                      \
+    bf16x8 a_[TM][NS], b_[TN][NS];                                                                      \
+    STCAT_UNROLL                                                                                        \
+    for (int s = 0; s < NS; ++s) {                                                                      \
+      STCAT_UNROLL                                                                                      \
+      for (int tm = 0; tm < TM; ++tm)                                                                   \
+        a_[tm][s] = *reinterpret_cast<const bf16x8*>(&(AS)[s * (BM * LDK) + (wm * TM * 32 + tm * 32 + l31) * LDK + ks * 16 + hi * 8]); \
+      STCAT_UNROLL                                                                                      \
+      for (int tn = 0; tn < TN; ++tn)                                                                   \
+        b_[tn][s] = *reinterpret_cast<const bf16x8*>(&(BS)[s * (BN * LDK) + (wn * TN * 32 + tn * 32 + l31) * LDK + ks * 16 + hi * 8]); \
+    }                                                                                                   \
+    STCAT_UNROLL                                                                                        \
+    for (int tm = 0; tm < TM; ++tm) {                                                                   \
+      STCAT_UNROLL                                                                                      \
+      for (int tn = 0; tn < TN; ++tn) {                                                                 \
+        STCAT_UNROLL                                                                                    \
+        for (int sa = NS - 1; sa >= 0; --sa) {                                                          \
+          STCAT_UNROLL                                                                                  \
+          for (int sb = NS - 1 - sa; sb >= 0; --sb)                                                     \
+            acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(a_[tm][sa], b_[tn][sb], acc[tm][tn]);                \
+        }                                                                                               \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+
+#define STCAT_BS_ACC_INIT                                     \
+  f32x16 acc[TM][TN];                                         \
+  STCAT_UNROLL                                                \
+  for (int i = 0; i < TM; ++i) {                              \
+    STCAT_UNROLL                                              \
+    for (int j = 0; j < TN; ++j) {                            \
+      STCAT_UNROLL                                            \
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;        \
+    }                                                         \
+  }
+
+// ---- R-type staging of a [ROWS x 32] tile: thread -> k4 = t&7, rows (t>>3) + 32*j -------------------
+#define STCAT_BS_STORE_R(DST, ROWS, REGS)                                                                \
+  STCAT_UNROLL                                                                                           \
+  for (int j = 0; j < (ROWS) / 32; ++j)                                                                  \
+    stcat_bs_split_store<NS>(&(DST)[((t >> 3) + 32 * j) * LDK + (t & 7) * 4], (ROWS) * LDK, (REGS)[j].x, \
+                             (REGS)[j].y, (REGS)[j].z, (REGS)[j].w);
+
+// ---- O-type staging of a [32(k) x ROWS] tile: block i = t + 256*j -> kgrp = i & 7 (4 k's), rowgrp = i >> 3 (4 rows).
+// A 16-lane group then writes 8 x 8 B = one contiguous 64-B row segment for each of two row groups 320 B apart
+// (conflict-free), and its global reads are 8 rows x 128 contiguous bytes (full lines).
+#define STCAT_BS_STORE_O(DST, ROWS, REGS)                                                                \
+  STCAT_UNROLL                                                                                           \
+  for (int j = 0; j < ((ROWS) * 2 + 255) / 256; ++j) {                                                   \
+    const int i = t + 256 * j;                                                                           \
+    if (i < (ROWS) * 2) {                                                                                \
+      const int kgrp = i & 7, rowgrp = i >> 3;                                      \
+      __bf16* d = &(DST)[(rowgrp * 4) * LDK + kgrp * 4];                                                 \
+      stcat_bs_split_store<NS>(d, (ROWS) * LDK, (REGS)[j][0].x, (REGS)[j][1].x, (REGS)[j][2].x, (REGS)[j][3].x);           \
+      stcat_bs_split_store<NS>(d + LDK, (ROWS) * LDK, (REGS)[j][0].y, (REGS)[j][1].y, (REGS)[j][2].y, (REGS)[j][3].y);     \
+      stcat_bs_split_store<NS>(d + 2 * LDK, (ROWS) * LDK, (REGS)[j][0].z, (REGS)[j][1].z, (REGS)[j][2].z, (REGS)[j][3].z); \
+      stcat_bs_split_store<NS>(d + 3 * LDK, (ROWS) * LDK, (REGS)[j][0].w, (REGS)[j][1].w, (REGS)[j][2].w, (REGS)[j][3].w); \
+    }                                                                                                    \
+  }
+
+// ---- gathered A operand (fwd / dgrad): byte offset of each staged row for the CURRENT filter tap, or
+// STCAT_BUF_OOB (hardware zero-fill).  Recomputed only when the tap changes; the channel offset inside the
+// tap rides in the scalar soffset of the buffer load.
+#define STCAT_BS_GATHER_DECL(ROWS)                                                                       \
+  int a_nb[(ROWS) / 32], a_bh[(ROWS) / 32], a_bw[(ROWS) / 32];                                           \
+  unsigned a_off[(ROWS) / 32];                                                                           \
+  int cur_tap = -1;                                                                                      \
+  STCAT_UNROLL                                                                                           \
+  for (int j = 0; j < (ROWS) / 32; ++j) {                                                                \
+    const int m = m0 + (t >> 3) + 32 * j;                                                                \
+    a_off[j] = STCAT_BUF_OOB;                                                                            \
+    if (m < p.M) {                                                                                       \
+      const int ohw = g.OH * g.OW;                                                                       \
+      const int nb = m / ohw, rem = m - nb * ohw, oh = rem / g.OW, ow = rem - oh * g.OW;                 \
+      a_nb[j] = nb; a_bh[j] = oh * g.mul + g.off; a_bw[j] = ow * g.mul + g.off;                          \
+    } else {                                                                                             \
+      a_nb[j] = -1; a_bh[j] = 0; a_bw[j] = 0;                                                            \
+    }                                                                                                    \
+  }
+
+#define STCAT_BS_LOAD_A_GATHER(KT, ROWS, SET)                                                            \
+  {                                                                                                      \
+    const int r0 = (KT) * BK, tap = r0 / g.C, c0 = r0 - tap * g.C;                                       \
+    if (tap != cur_tap) {                                                                                \
+      cur_tap = tap;                                                                                     \
+      const int kh = tap / g.KW, kw = tap - kh * g.KW;                                                   \
+      STCAT_UNROLL                                                                                       \
+      for (int j = 0; j < (ROWS) / 32; ++j) {                                                            \
+        const long pix = a_nb[j] < 0 ? -1 : stcat_gather_pix(g, a_nb[j], a_bh[j], a_bw[j], kh, kw);      \
+        a_off[j] = pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (t & 7) * 16;                         \
+      }                                                                                                  \
+    }                                                                                                    \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < (ROWS) / 32; ++j) ra[SET][j] = stcat_buf_ld4(bufA, a_off[j], (unsigned)c0 * 4);  \
+  }
+
+// Software pipeline shared by the three kernels: LDS double buffer + two register sets, so the global loads of
+// K-tile kt+2 are in flight during the MFMA phases of tiles kt and kt+1.
+#define STCAT_BS_PIPELINE(LOAD, STORE)                                                                   \
+  LOAD(0, 0)                                                                                             \
+  if (nk > 1) { LOAD(1, 1) }                                                                             \
+  STORE(0, 0)                                                                                            \
+  __syncthreads();                                                                                       \
+  for (int kt = 0; kt < nk; kt += 2) {                                                                   \
+    if (kt + 2 < nk) { LOAD(kt + 2, 0) }                                                                 \
+    STCAT_BS_COMPUTE(As[0], Bs[0])                                                                       \
+    if (kt + 1 < nk) { STORE(1, 1) }                                                                     \
+    __syncthreads();                                                                                     \
+    if (kt + 1 >= nk) break;                                                                             \
+    if (kt + 3 < nk) { LOAD(kt + 3, 1) }                                                                 \
+    STCAT_BS_COMPUTE(As[1], Bs[1])                                                                       \
+    if (kt + 2 < nk) { STORE(0, 0) }                                                                     \
+    __syncthreads();                                                                                     \
+  }
+
+#define STCAT_BS_PROLOGUE                                                                                \
+  constexpr int BK = 32, LDK = STCAT_BS_LDK, TM = BM / 64, TN = BN / 64;                                 \
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][NS * BM * LDK];                                   \
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NS * BN * LDK];                                   \
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;                                               \
+  const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;                              \
+  const int num_n = p.N / BN;                                                                            \
+  const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);                                                  \
+  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;                                                \
+  const IgemmGeom g = p.g;                                                                               \
+  const stcat_buf_t bufA = stcat_make_buf(p.A, p.a_bytes);                                               \
+  const stcat_buf_t bufB = stcat_make_buf(p.B, p.b_bytes);
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
+  STCAT_BS_PROLOGUE
+  STCAT_BS_GATHER_DECL(BM)
+  STCAT_BS_ACC_INIT
+  unsigned b_off[BN / 32];
+  STCAT_UNROLL
+  for (int j = 0; j < BN / 32; ++j) b_off[j] = (unsigned)((n0 + (t >> 3) + 32 * j) * p.ldb + (t & 7) * 4) * 4;
+  float4 ra[2][BM / 32], rb[2][BN / 32];
+  const int nk = p.K / BK;
+#define STCAT_BSF_LOAD(KT, SET)                                                                          \
+  STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
+  STCAT_UNROLL                                                                                           \
+  for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bufB, b_off[j], (unsigned)(KT) * (BK * 4));
+#define STCAT_BSF_STORE(SET, BUF) \
+  STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
+  STCAT_BS_PIPELINE(STCAT_BSF_LOAD, STCAT_BSF_STORE)
+#undef STCAT_BSF_LOAD
+#undef STCAT_BSF_STORE
+  STCAT_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    STCAT_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m < p.M) {
+          float val = acc[tm][tn][r] * sc + bi;
+          if (p.res) val += p.res[(long)m * p.ldr + n];
+          if (p.relu) val = fmaxf(val, 0.f);
+          p.C[(long)m * p.ldc + n] = val;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dgrad: A = gathered dY (R), B[k=(tap,co)][n=ci] = W[co][tap][ci] (O)
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
+  STCAT_BS_PROLOGUE
+  constexpr int JB = (BN * 2 + 255) / 256;
+  STCAT_BS_GATHER_DECL(BM)
+  STCAT_BS_ACC_INIT
+  unsigned b_off[JB][4];
+  STCAT_UNROLL
+  for (int j = 0; j < JB; ++j) {
+    const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;
+    STCAT_UNROLL
+    for (int e = 0; e < 4; ++e)
+      b_off[j][e] = i < BN * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + n0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
+  }
+  float4 ra[2][BM / 32], rb[2][JB][4];
+  const int nk = p.K / BK;
+#define STCAT_BSD_LOAD(KT, SET)                                                                          \
+  STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
+  {                                                                                                      \
+    const int r0 = (KT) * BK, tap = r0 / g.C, co0 = r0 - tap * g.C;                                      \
+    const unsigned soff = (unsigned)(co0 * p.ldb + tap * p.N) * 4;                                       \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < JB; ++j) {                                                                       \
+      STCAT_UNROLL                                                                                       \
+      for (int e = 0; e < 4; ++e) rb[SET][j][e] = stcat_buf_ld4(bufB, b_off[j][e], soff);                \
+    }                                                                                                    \
+  }
+#define STCAT_BSD_STORE(SET, BUF) \
+  STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_O(Bs[BUF], BN, rb[SET])
+  STCAT_BS_PIPELINE(STCAT_BSD_LOAD, STCAT_BSD_STORE)
+#undef STCAT_BSD_LOAD
+#undef STCAT_BSD_STORE
+  STCAT_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
+    STCAT_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (m < p.M) {
+          float val = acc[tm][tn][r];
+          if (p.res) val += p.res[(long)m * p.ldr + n];
+          p.C[(long)m * p.ldc + n] = val;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: A[k=pixel][row=co] = dY (O), B[k=pixel][col=(tap,ci)] = gathered X (O); split-K over grid.z, atomics
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
+  STCAT_BS_PROLOGUE
+  constexpr int JA = (BM * 2 + 255) / 256, JB = (BN * 2 + 255) / 256;
+  const int tap = n0 / g.C, ci0 = n0 - tap * g.C;
+  const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  const int red0 = blockIdx.z * p.k_chunk;
+  const int red1 = min(p.K, red0 + p.k_chunk);
+  const int ohw = g.OH * g.OW;
+  const int nk = (red1 - red0 + BK - 1) / BK;
+  if (nk <= 0) return;
+  STCAT_BS_ACC_INIT
+  unsigned a_off[JA][4];
+  STCAT_UNROLL
+  for (int j = 0; j < JA; ++j) {
+    const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;
+    STCAT_UNROLL
+    for (int e = 0; e < 4; ++e)
+      a_off[j][e] = i < BM * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + m0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
+  }
+  float4 ra[2][JA][4], rb[2][JB][4];
+  // gathered B: pixel coordinates of this thread's first reduction row, advanced by 32 pixels per K-tile
+  // without divisions (the loads are issued in increasing K-tile order)
+  int g_nb[JB], g_oh[JB], g_ow[JB];
+  STCAT_UNROLL
+  for (int j = 0; j < JB; ++j) {
+    const int m = red0 + ((t + 256 * j) & 7) * 4;
+    g_nb[j] = m / ohw;
+    const int rem = m - g_nb[j] * ohw;
+    g_oh[j] = rem / g.OW;
+    g_ow[j] = rem - g_oh[j] * g.OW;
+  }
+#define STCAT_BSW_LOAD(KT, SET)                                                                          \
+  {                                                                                                      \
+    const int mbase = red0 + (KT) * BK;                                                                  \
+    const unsigned soff = (unsigned)mbase * (unsigned)p.ldb * 4u;                                        \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < JA; ++j) {                                                                       \
+      const int kgrp = (t + 256 * j) & 7;                                                                \
+      STCAT_UNROLL                                                                                       \
+      for (int e = 0; e < 4; ++e)                                                                        \
+        ra[SET][j][e] = stcat_buf_ld4(bufA, mbase + kgrp * 4 + e < red1 ? a_off[j][e] : STCAT_BUF_OOB, soff); \
+    }                                                                                                    \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < JB; ++j) {                                                                       \
+      const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;                                          \
+      int nb = g_nb[j], oh = g_oh[j], ow = g_ow[j];                                                      \
+      STCAT_UNROLL                                                                                       \
+      for (int e = 0; e < 4; ++e) {                                                                      \
+        const int m = mbase + kgrp * 4 + e;                                                              \
+        long pix = -1;                                                                                   \
+        if (m < red1 && i < BN * 2) pix = stcat_gather_pix(g, nb, oh * g.mul + g.off, ow * g.mul + g.off, kh, kw); \
+        rb[SET][j][e] = stcat_buf_ld4(bufB, pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (ci0 + rowgrp * 4) * 4, 0u); \
+        if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++nb; } }                                \
+      }                                                                                                  \
+      /* advance this thread's first row by BK = 32 pixels for the next K-tile */                        \
+      ow = g_ow[j] + BK;                                                                                 \
+      oh = g_oh[j];                                                                                      \
+      nb = g_nb[j];                                                                                      \
+      while (ow >= g.OW) { ow -= g.OW; if (++oh == g.OH) { oh = 0; ++nb; } }                             \
+      g_nb[j] = nb; g_oh[j] = oh; g_ow[j] = ow;                                                          \
+    }                                                                                                    \
+  }
+#define STCAT_BSW_STORE(SET, BUF) \
+  STCAT_BS_STORE_O(As[BUF], BM, ra[SET]) STCAT_BS_STORE_O(Bs[BUF], BN, rb[SET])
+  STCAT_BS_PIPELINE(STCAT_BSW_LOAD, STCAT_BSW_STORE)
+#undef STCAT_BSW_LOAD
+#undef STCAT_BSW_STORE
+  STCAT_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
+    STCAT_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        atomicAdd(&p.C[(long)m * p.ldc + n], acc[tm][tn][r]);
+      }
+    }
+  }
+}

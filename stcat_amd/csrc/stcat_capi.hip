@@ -7,6 +7,7 @@
 #include "../../include/stcat_hip.h"
 #include "attention.h"
 #include "igemm.h"
+#include "igemm_bs.h"
 #include "pointwise.h"
 
 namespace {
@@ -33,6 +34,8 @@ inline int launch_status() {
 }
 #endif
 
+// byte extent of an operand for the 32-bit buffer loads; 0xFFFFFFFF marks 'too large' (fp32 kernels are used then)
+inline unsigned bytes_of(long elems) { return elems * 4 >= 0x7FFFFFFFl ? 0xFFFFFFFFu : (unsigned)(elems * 4); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline int grid_for(long n, int per_block, int cap = 4096) {
@@ -69,16 +72,38 @@ void pick_tile(int M, int N, int& BM, int& BN) {
   }
 }
 
+int g_mma_mode = 0;  // 0: fp32 MFMA (exact), 2: split-bf16 x3, 3: split-bf16 x6   (stcat_set_mma_mode)
+
+#define STCAT_TILE_SWITCH(KERNEL, GRID)                                                        \
+  if (BM == 128 && BN == 128) {                                                                \
+    STCAT_LAUNCH((KERNEL<128, 128>), GRID, dim3(256), 0, st, p);                               \
+  } else if (BM == 128) {                                                                      \
+    STCAT_LAUNCH((KERNEL<128, 64>), GRID, dim3(256), 0, st, p);                                \
+  } else {                                                                                     \
+    STCAT_LAUNCH((KERNEL<64, 64>), GRID, dim3(256), 0, st, p);                                 \
+  }
+#define STCAT_TILE_SWITCH_BS(KERNEL, GRID, NS_)                                                \
+  if (BM == 128 && BN == 128) {                                                                \
+    STCAT_LAUNCH((KERNEL<128, 128, NS_>), GRID, dim3(256), 0, st, p);                          \
+  } else if (BM == 128) {                                                                      \
+    STCAT_LAUNCH((KERNEL<128, 64, NS_>), GRID, dim3(256), 0, st, p);                           \
+  } else {                                                                                     \
+    STCAT_LAUNCH((KERNEL<64, 64, NS_>), GRID, dim3(256), 0, st, p);                            \
+  }
+
+// the split-bf16 kernels step K by 32 and need a K step to stay inside one filter tap
+inline bool bs_ok(const IgemmParams& p) {
+  return g_mma_mode != 0 && p.K % 32 == 0 && p.g.C % 32 == 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu;
+}
+
 int launch_fwd(const IgemmParams& p, hipStream_t st) {
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
-  const int blocks = cdiv(p.M, BM) * (p.N / BN);
-  if (BM == 128 && BN == 128) {
-    STCAT_LAUNCH((igemm_fwd_kernel<128, 128>), dim3(blocks), dim3(256), 0, st, p);
-  } else if (BM == 128) {
-    STCAT_LAUNCH((igemm_fwd_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, p);
+  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  if (bs_ok(p)) {
+    if (g_mma_mode == 3) { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 3) } else { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 2) }
   } else {
-    STCAT_LAUNCH((igemm_fwd_kernel<64, 64>), dim3(blocks), dim3(256), 0, st, p);
+    STCAT_TILE_SWITCH(igemm_fwd_kernel, grid)
   }
   return launch_status();
 }
@@ -86,13 +111,11 @@ int launch_fwd(const IgemmParams& p, hipStream_t st) {
 int launch_dgrad(const IgemmParams& p, hipStream_t st) {
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
-  const int blocks = cdiv(p.M, BM) * (p.N / BN);
-  if (BM == 128 && BN == 128) {
-    STCAT_LAUNCH((igemm_dgrad_kernel<128, 128>), dim3(blocks), dim3(256), 0, st, p);
-  } else if (BM == 128) {
-    STCAT_LAUNCH((igemm_dgrad_kernel<128, 64>), dim3(blocks), dim3(256), 0, st, p);
+  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  if (bs_ok(p)) {
+    if (g_mma_mode == 3) { STCAT_TILE_SWITCH_BS(igemm_bs_dgrad_kernel, grid, 3) } else { STCAT_TILE_SWITCH_BS(igemm_bs_dgrad_kernel, grid, 2) }
   } else {
-    STCAT_LAUNCH((igemm_dgrad_kernel<64, 64>), dim3(blocks), dim3(256), 0, st, p);
+    STCAT_TILE_SWITCH(igemm_dgrad_kernel, grid)
   }
   return launch_status();
 }
@@ -107,16 +130,25 @@ int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   int chunk = cdiv(red, nsplit);
-  chunk = ((chunk + 15) / 16) * 16;
+  chunk = ((chunk + 31) / 32) * 32;
   nsplit = cdiv(red, chunk);
   p.M = rows;
   p.N = cols;
   p.K = red;
   p.k_chunk = chunk;
-  if (big) {
-    STCAT_LAUNCH((igemm_wgrad_kernel<128, 128>), dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
+  const dim3 grid(tiles, 1, nsplit);
+  if (g_mma_mode != 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu) {
+    if (big) {
+      if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_wgrad_kernel<128, 128, 3>), grid, dim3(256), 0, st, p); }
+      else { STCAT_LAUNCH((igemm_bs_wgrad_kernel<128, 128, 2>), grid, dim3(256), 0, st, p); }
+    } else {
+      if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_wgrad_kernel<64, 64, 3>), grid, dim3(256), 0, st, p); }
+      else { STCAT_LAUNCH((igemm_bs_wgrad_kernel<64, 64, 2>), grid, dim3(256), 0, st, p); }
+    }
+  } else if (big) {
+    STCAT_LAUNCH((igemm_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, p);
   } else {
-    STCAT_LAUNCH((igemm_wgrad_kernel<64, 64>), dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
+    STCAT_LAUNCH((igemm_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, p);
   }
   return launch_status();
 }
@@ -132,6 +164,12 @@ IgemmGeom conv_geom_fwd(int H, int W, int C, int ld, int OH, int OW, int KH, int
 extern "C" {
 
 int stcat_version(void) { return 100; }
+int stcat_set_mma_mode(int mode) {
+  if (mode != 0 && mode != 2 && mode != 3) return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
+  g_mma_mode = mode;
+  return 0;
+}
+int stcat_get_mma_mode(void) { return g_mma_mode; }
 int stcat_debug_force_tile(int bm, int bn) {
   const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
   if (!ok) return fail("debug_force_tile: unsupported tile %dx%d", bm, bn);
@@ -179,6 +217,7 @@ int stcat_conv_fwd(const float* x, const float* w, const float* scale, const flo
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   IgemmParams p = {};
   p.A = x; p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = res;
+  p.a_bytes = bytes_of((long)n * H * W * Cin); p.b_bytes = bytes_of((long)Cout * KH * KW * Cin);
   p.M = n * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.c_group = p.M; p.c_group_stride = 0; p.relu = relu;
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
@@ -192,6 +231,7 @@ int stcat_conv_dgrad(const float* g, const float* w, const float* add, float* dx
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   IgemmParams p = {};
   p.A = g; p.B = w; p.C = dx; p.res = add;
+  p.a_bytes = bytes_of((long)n * OH * OW * Cout); p.b_bytes = bytes_of((long)Cout * KH * KW * Cin);
   p.M = n * H * W; p.N = Cin; p.K = KH * KW * Cout; p.ldb = KH * KW * Cin; p.ldc = Cin; p.ldr = Cin;
   p.c_group = p.M; p.relu = 0;
   // gathered tensor = g [n,OH,OW,Cout]; rows enumerate input pixels (hi, wi): ho = (hi + pad - kh) / stride
@@ -209,6 +249,7 @@ int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, in
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   IgemmParams p = {};
   p.A = g; p.B = x; p.C = dw; p.ldb = Cout; p.ldc = KH * KW * Cin;
+  p.a_bytes = bytes_of((long)n * OH * OW * Cout); p.b_bytes = bytes_of((long)n * H * W * Cin);
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
   return launch_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
 }
@@ -248,6 +289,7 @@ int stcat_linear_fwd(const float* x, const float* w, const float* bias, const fl
   if (M <= 0) return fail("linear_fwd: M=%d", M);
   IgemmParams p = {};
   p.A = x; p.B = w; p.C = y; p.scale = nullptr; p.bias = bias; p.res = res;
+  p.a_bytes = bytes_of((long)(M - 1) * ldx + K); p.b_bytes = bytes_of((long)N * K);
   p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = ldy; p.ldr = ldr;
   p.c_group = c_group > 0 ? c_group : M;
   p.c_group_stride = (int)c_group_stride;
@@ -262,6 +304,7 @@ int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* 
   if (ldg % 4 != 0 || !aligned16(g) || !aligned16(w)) return fail("linear_dgrad: g/w must be 16-byte aligned rows");
   IgemmParams p = {};
   p.A = g; p.B = w; p.C = dx; p.res = add;
+  p.a_bytes = bytes_of((long)(M - 1) * ldg + N); p.b_bytes = bytes_of((long)N * K);
   p.M = M; p.N = K; p.K = N; p.ldb = K; p.ldc = lddx; p.ldr = lddx;
   p.c_group = M; p.relu = 0;
   IgemmGeom q;
@@ -277,6 +320,7 @@ int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, 
   if (ldg % 4 != 0 || ldx % 4 != 0 || !aligned16(g) || !aligned16(x)) return fail("linear_wgrad: unaligned");
   IgemmParams p = {};
   p.A = g; p.B = x; p.C = dw; p.ldb = ldg; p.ldc = K;
+  p.a_bytes = bytes_of((long)(M - 1) * ldg + N); p.b_bytes = bytes_of((long)(M - 1) * ldx + K);
   p.g = conv_geom_fwd(1, 1, K, ldx, 1, 1, 1, 1, 1, 0);
   return launch_wgrad(p, N, K, M, (hipStream_t)stream);
 }

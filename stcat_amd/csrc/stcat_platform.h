@@ -7,6 +7,7 @@
 #ifdef STCAT_EMU
 #include "hip_emu.h"
 #define STCAT_MFMA_32x32x2(a, b, c) emu_mfma_f32_32x32x2f32((a), (b), (c))
+#define STCAT_MFMA_BF16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
 #define STCAT_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   emu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
 #define STCAT_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(emu::t_dynshared)
@@ -15,13 +16,40 @@
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define STCAT_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define STCAT_MFMA_BF16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define STCAT_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
 #define STCAT_DYN_SHARED(type, name) \
   extern __shared__ __attribute__((aligned(16))) char stcat_dyn_smem_[]; \
   type* name = reinterpret_cast<type*>(stcat_dyn_smem_)
 #define STCAT_UNROLL _Pragma("unroll")
+#endif
+
+// ---- bounds-checked 16-byte loads through a buffer descriptor: an offset at or beyond `bytes` returns
+// zeros in hardware (raw buffer load, stride 0), which is how padding / stride-lattice / tail rows of the
+// implicit-GEMM gathers are zero-filled without exec-mask branches.  Offsets are 32-bit byte offsets.
+#define STCAT_BUF_OOB 0x80000000u
+#ifdef STCAT_EMU
+struct stcat_buf_t { const char* base; unsigned bytes; };
+static inline stcat_buf_t stcat_make_buf(const void* p, unsigned bytes) { return stcat_buf_t{(const char*)p, bytes}; }
+static inline float4 stcat_buf_ld4(stcat_buf_t b, unsigned voff, unsigned soff) {
+  const unsigned long off = (unsigned long)voff + soff;
+  if (voff >= STCAT_BUF_OOB || off + 16 > b.bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(b.base + off);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t stcat_buf_t;
+static __device__ __forceinline__ stcat_buf_t stcat_make_buf(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float4 stcat_buf_ld4(stcat_buf_t b, unsigned voff, unsigned soff) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
 #endif
 
 #define STCAT_WAVE 64

@@ -52,6 +52,7 @@ struct WaveState {
   int gen = 0, arrived = 0;
   float xa[64], xb[64];
   int xi[64];
+  float xa8[64][8], xb8[64][8];
 };
 struct BlockCtx {
   std::vector<Fiber> fibers;
@@ -224,6 +225,28 @@ static inline f32x16 emu_mfma_f32_32x32x2f32(float a, float b, f32x16 c) {
     float acc = c[r];
     acc = fmaf(w.xa[i], w.xb[j], acc);
     acc = fmaf(w.xa[i + 32], w.xb[j + 32], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[l&31][8*(l>>5)+j] and B[8*(l>>5)+j][l&31], j < 8.
+static inline f32x16 emu_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  emu::WaveState& w = emu::wave();
+  float (*sa)[8] = w.xa8;
+  float (*sb)[8] = w.xb8;
+  const int l = emu::lane();
+  for (int j = 0; j < 8; ++j) { sa[l][j] = (float)a[j]; sb[l][j] = (float)b[j]; }
+  emu::wave_sync();
+  const int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h)
+      for (int j = 0; j < 8; ++j) acc = fmaf(sa[i + 32 * h][j], sb[col + 32 * h][j], acc);
     c[r] = acc;
   }
   emu::wave_sync();

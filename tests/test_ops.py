@@ -345,3 +345,51 @@ def _temporal_argmax(dev, big):
         _, _, flat = O.post_process(sted, boxes, torch.ones(T, 2), list(range(T)), dur)
         got = ops.temporal_map_argmax(sted.to(dev), [dur]).cpu()
         assert (int(got[0, 0]), int(got[0, 1])) == (flat // T, flat % T), (T, dur, got, flat)
+
+
+# ---- split-bf16 GEMM modes (stcat_set_mma_mode) ---------------------------------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def mma_mode(mode, tol):
+    global TOL
+    old_tol, old_mode = TOL, L.get_mma_mode()
+    L.set_mma_mode(mode)
+    TOL = tol
+    try:
+        yield
+    finally:
+        L.set_mma_mode(old_mode)
+        TOL = old_tol
+
+
+def _gemm_family(dev, big):
+    _linear_case(dev, 70, 64, 64, relu=True, res=True)
+    _linear_case(dev, 130, 128, 128, relu=False, res=False, tile=(128, 128))
+    _linear_case(dev, 130, 128, 64, relu=True, res=True, tile=(128, 64))
+    _conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True)
+    _conv_case(dev, 1, 8, 8, 64, 64, 3, 2, 1, relu=True, res=False)
+    _conv_case(dev, 1, 9, 7, 64, 128, 1, 2, 0, relu=False, res=False)
+    _conv_case(dev, 2, 5, 5, 128, 128, 1, 1, 0, relu=True, res=True, tile=(128, 128))
+    _conv_case(dev, 1, 12, 11, 128, 128, 3, 1, 1, relu=True, res=False, tile=(128, 64))
+    if big:
+        _linear_case(dev, 13248, 2048, 256, relu=True, res=False)
+        _linear_case(dev, 13248, 256, 2048, relu=False, res=True)
+        _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
+        _conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False)
+        _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True)
+
+
+@both
+def _gemm_bf16x3(dev, big):
+    # products carry ~2^-16 relative error (two bf16 pieces per operand)
+    with mma_mode("bf16x3", 1e-3):
+        _gemm_family(dev, big)
+
+
+@both
+def _gemm_bf16x6(dev, big):
+    # three pieces per operand: fp32-class products
+    with mma_mode("bf16x6", 2e-4):
+        _gemm_family(dev, big)
