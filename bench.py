@@ -26,7 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stcat_amd import _lib, synth  # noqa: E402
+from stcat_amd import _lib, ops, synth  # noqa: E402
 from stcat_amd.dist import GradBucketReducer  # noqa: E402
 from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
 from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
@@ -164,6 +164,7 @@ def main():
     synth.fill_module_(model)
     model.to(dev)
     reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0)
+    arena = ops.enable_zero_arena(dev, 120_000_000)  # weight-gradient accumulators etc.: one memset per step
 
     frames = synth.synth_frames(T, res, seed=1000 * 3 + rank).to(dev)
     mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
@@ -173,6 +174,7 @@ def main():
 
     def step():
         reducer.zero_grad()
+        arena.reset()
         out = model(videos, ["synthetic"])
         losses = criterion(out, targets, [T])
         total = sum(losses[k] * wd[k] for k in losses)

@@ -1,9 +1,10 @@
 """Data-parallel gradient exchange: one video per GPU, one process per GPU (scripts/train_net.py:31-36 wraps
 the reference model in torch DDP with find_unused_parameters=True).  Here instead:
 
-* every trainable, *live* parameter's ``.grad`` is a view into a few large flat fp32 buckets laid out in
-  backward-readiness order (heads -> decoders -> encoder -> input_proj -> layer4 -> layer2), so autograd
-  accumulates straight into the communication buffers;
+* trainable, *live* parameters are grouped into a few large flat fp32 buckets laid out in
+  backward-readiness order (heads -> decoders -> encoder -> input_proj -> layer4 -> layer2); ``.grad`` is reset
+  to None each step so autograd simply takes every gradient tensor (no per-parameter add kernel), and a
+  completed bucket is gathered with ONE fused multi-tensor copy;
 * the 14 parameter tensors that never receive a gradient in the reference (ground_encoder.fusion.*,
   decoder.layers.*.ca_qtime_proj.*) are excluded statically instead of being discovered
   by a graph walk every step;
@@ -35,6 +36,7 @@ class GradBucketReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = live_trainable(model.named_parameters())[::-1]  # reverse registration ~ readiness order
+        self.params = [p for _, p in params]
         cap = int(bucket_mb * (1 << 20) // 4)
         self.buckets: List[Dict] = []
         cur, cur_n = [], 0
@@ -49,32 +51,47 @@ class GradBucketReducer:
         self._owner = {}
         for bi, b in enumerate(self.buckets):
             dev = b["params"][0][1].device
-            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev)
+            # the flat communication buffer only exists when there is somebody to talk to
+            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev) if self.world > 1 else None
+            b["views"] = []
             off = 0
             for n, p in b["params"]:
-                view = b["flat"][off:off + p.numel()]
-                # keep the parameter's memory format (conv weights are channels_last)
-                g = torch.as_strided(view, p.shape, p.stride()) if p.is_contiguous(memory_format=torch.channels_last) \
-                    and p.dim() == 4 and not p.is_contiguous() else view.view(p.shape)
-                p.grad = g
+                if self.world > 1:
+                    view = b["flat"][off:off + p.numel()]
+                    # keep the parameter's memory format (conv weights are channels_last)
+                    cl = p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+                    b["views"].append(torch.as_strided(view, p.shape, p.stride()) if cl else view.view(p.shape))
                 off += p.numel()
                 self._owner[p] = bi
                 p.register_post_accumulate_grad_hook(self._on_grad)
             b["pending"] = len(b["params"])
             b["work"] = None
-        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=self.buckets[0]["flat"].device) \
-            if extra_numel else None
+        dev0 = self.buckets[0]["params"][0][1].device
+        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=dev0) if (extra_numel and self.world > 1) else None
         self._extra_work = None
+        self.extra_numel = extra_numel
 
     # ---- per step -------------------------------------------------------------------------------
     def zero_grad(self):
+        """grads are set to None: autograd then *takes* each gradient tensor instead of running an add kernel
+        per parameter; buckets are gathered with one fused multi-tensor copy when they complete."""
+        for p in self.params:
+            p.grad = None
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["work"] = None
 
     def _launch(self, b):
         if self.world > 1:
+            srcs, dsts = [], []
+            for (n, p), v in zip(b["params"], b["views"]):
+                if p.grad is not None:
+                    srcs.append(p.grad)
+                    dsts.append(v)
+                else:
+                    v.zero_()
+            if srcs:
+                torch._foreach_copy_(dsts, srcs)
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b["pending"] = -1
 
@@ -85,19 +102,23 @@ class GradBucketReducer:
             self._launch(b)
 
     def finish(self):
-        """Block the current stream until every bucket is reduced, then average."""
-        if self.extra is not None and self.world > 1:
+        """Block the current stream until every bucket is reduced and averaged; afterwards every live
+        parameter's .grad is (a view of) the averaged gradient."""
+        if self.world == 1:
+            return
+        if self.extra is not None:
             self._extra_work = dist.all_reduce(self.extra, group=self.group, async_op=True)
         for b in self.buckets:
             if b["pending"] >= 0:  # a parameter got no gradient this step: reduce what is there
                 self._launch(b)
-        if self.world > 1:
-            for b in self.buckets:
-                b["work"].wait()
-                b["flat"].mul_(1.0 / self.world)
-            if self._extra_work is not None:
-                self._extra_work.wait()
+        for b in self.buckets:
+            b["work"].wait()
+            b["flat"].mul_(1.0 / self.world)
+            for (n, p), v in zip(b["params"], b["views"]):
+                p.grad = v
+        if self._extra_work is not None:
+            self._extra_work.wait()
 
     @property
     def message_bytes(self) -> int:
-        return 4 * (sum(b["numel"] for b in self.buckets) + (self.extra.numel() if self.extra is not None else 0))
+        return 4 * (sum(b["numel"] for b in self.buckets) + self.extra_numel)

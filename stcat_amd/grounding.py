@@ -233,8 +233,9 @@ class TransformerDecoderLayer(nn.Module):
         self.norm4 = nn.LayerNorm(d_model)
         self.nhead = nhead
 
-    def run(self, tgt, mem2d, n, kpm, pos2d, query_pos, time_embed, query_sine, first: bool):
-        """tgt/query_pos/time_embed/query_sine [T,256]; mem2d/pos2d [n*S',256] frame-major rows."""
+    def run(self, tgt, kc, kpos, vv, kpm, query_pos, time_embed, query_sine, first: bool):
+        """tgt/query_pos/time_embed/query_sine [T,256]; kc/kpos/vv [n,S',256] = this layer's ca_kcontent_proj(memory),
+        ca_kpos_proj(pos), ca_v_proj(memory) — column blocks of the layer-batched projections (QueryDecoder.run)."""
         T, D = tgt.shape
         hd = D // self.nhead
         W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
@@ -249,18 +250,13 @@ class TransformerDecoderLayer(nn.Module):
         a, _ = ops.mha_self(qp[None], kp_[None], vp[None], None, hd ** -0.5)
         tgt = _ln(self.norm1, ops.linear(a[0], self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt))
 
-        kpos = _lin(self.ca_kpos_proj, pos2d)                                                # :358
         qc = _lin(self.ca_qcontent_proj, tgt)
         if first:                                                                            # :360-366
             qc = ops.add(qc, _lin(self.ca_qpos_proj, query_pos))
-            kc = _lin(self.ca_kcontent_proj, mem2d, res=kpos)
-        else:
-            kc = _lin(self.ca_kcontent_proj, mem2d)
-        vv = _lin(self.ca_v_proj, mem2d)
+            kpos = kpos.contiguous()  # k1 and k2 must share one leading dimension in the kernel
+            kc = ops.add(kc.contiguous(), kpos)
         qs = _lin(self.ca_qpos_sine_proj, query_sine)                                        # :369
-        S = mem2d.shape[0] // n
-        a = ops.attn_q1(qc, qs, kc.view(n, S, D), kpos.view(n, S, D), vv.view(n, S, D), kpm,
-                        (2 * hd) ** -0.5)                                                    # :368-409
+        a = ops.attn_q1(qc, qs, kc, kpos, vv, kpm, (2 * hd) ** -0.5)                         # :368-409
         tgt = _ln(self.norm3, _lin(self.cross_attn.out_proj, a, res=tgt))                    # :431-432
         h = _lin(self.linear1, tgt, relu=True)
         return _ln(self.norm4, _lin(self.linear2, h, res=tgt))
@@ -281,10 +277,21 @@ class TransformerDecoder(nn.Module):
         for layer_id in range(num_layers - 1):
             self.layers[layer_id + 1].ca_qpos_proj = None                                    # :166-167
 
-    def run(self, mem2d, n, kpm, pos2d, anchor, time_embed):
-        """anchor [T,4] (sigmoid-ed template), returns hs [L,T,256], refs [L,T,4]."""
+    def memory_projections(self, memory, pos):
+        """ca_kcontent_proj / ca_v_proj of `memory` and ca_kpos_proj of `pos` for ALL layers as three GEMMs
+        with N = layers*256 (query_decoder.py:355-358 computes them layer by layer on the same inputs)."""
+        L_ = self.num_layers
+        cat = lambda nm, leaf: torch.cat([getattr(getattr(l, nm), leaf) for l in self.layers], dim=0)  # noqa: E731
+        kc = ops.split_cols(ops.linear(memory, cat("ca_kcontent_proj", "weight"), cat("ca_kcontent_proj", "bias")), L_)
+        vv = ops.split_cols(ops.linear(memory, cat("ca_v_proj", "weight"), cat("ca_v_proj", "bias")), L_)
+        kp = ops.split_cols(ops.linear(pos, cat("ca_kpos_proj", "weight"), cat("ca_kpos_proj", "bias")), L_)
+        return kc, kp, vv
+
+    def run(self, memory, kpm, pos, anchor, time_embed):
+        """memory/pos [n,S',256]; anchor [T,4] (sigmoid-ed template); returns hs [L,T,256], refs [L,T,4]."""
         T = anchor.shape[0]
-        out = torch.zeros(T, self.d_model, device=mem2d.device)
+        kc, kp, vv = self.memory_projections(memory, pos)
+        out = torch.zeros(T, self.d_model, device=memory.device)
         inter, refs = [], [anchor]
         for i, layer in enumerate(self.layers):
             sine = ops.sine_embed(anchor)                                                    # [T,512]  :190
@@ -292,7 +299,7 @@ class TransformerDecoder(nn.Module):
             sine_q = sine[:, : self.d_model]
             if i > 0:
                 sine_q = ops.mul(sine_q.contiguous(), self.query_scale(out))                 # :194-200
-            out = layer.run(out, mem2d, n, kpm, pos2d, query_pos, time_embed, sine_q, i == 0)
+            out = layer.run(out, kc[i], kp[i], vv[i], kpm, query_pos, time_embed, sine_q, i == 0)
             tmp = self.bbox_embed(out)                                                       # :212
             new_anchor = ops.sigmoid(ops.add(tmp, ops.inverse_sigmoid(anchor)))              # :213-214
             if i != self.num_layers - 1:
@@ -316,7 +323,8 @@ class TimeDecoderLayer(nn.Module):
         self.norm4 = nn.LayerNorm(d_model)
         self.nhead = nhead
 
-    def run(self, tgt, mem2d, mem_pos2d, n, kpm, query_pos, qpos_time):
+    def run(self, tgt, kc, vv, kpm, query_pos, qpos_time):
+        """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory."""
         T, D = tgt.shape
         hd = D // self.nhead
         W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
@@ -327,10 +335,7 @@ class TimeDecoderLayer(nn.Module):
         tgt = _ln(self.norm1, ops.linear(a[0], self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt))
         Wc, Bc = self.cross_attn_image.in_proj_weight, self.cross_attn_image.in_proj_bias
         qc = ops.linear(ops.add(tgt, query_pos), Wc[:D], Bc[:D])                             # :633-634
-        kc = ops.linear(mem_pos2d, Wc[D:2 * D], Bc[D:2 * D])                                 # key = memory + pos
-        vv = ops.linear(mem2d, Wc[2 * D:], Bc[2 * D:])
-        S = mem2d.shape[0] // n
-        a = ops.attn_q1(qc, None, kc.view(n, S, D), None, vv.view(n, S, D), kpm, hd ** -0.5)
+        a = ops.attn_q1(qc, None, kc, None, vv, kpm, hd ** -0.5)
         tgt = _ln(self.norm3, ops.linear(a, self.cross_attn_image.out_proj.weight,
                                          self.cross_attn_image.out_proj.bias, res=tgt))
         h = _lin(self.linear1, tgt, relu=True)
@@ -346,13 +351,23 @@ class TimeDecoder(nn.Module):
         self.norm = nn.LayerNorm(d_model)
         self.d_model = d_model
 
-    def run(self, mem2d, mem_pos2d, n, kpm, query_pos, time_pos):
+    def run(self, memory, mem_pos, kpm, query_pos, time_pos):
+        """memory, mem_pos (= memory + pos) [n,S',256].  The key/value in-projections of all layers run as two
+        GEMMs with N = layers*256 (query_decoder.py:633-639 applies them per layer to the same tensors)."""
         T = query_pos.shape[0]
-        out = torch.zeros(T, self.d_model, device=mem2d.device)
+        D = self.d_model
+        nl = len(self.layers)
+        Wk = torch.cat([l.cross_attn_image.in_proj_weight[D:2 * D] for l in self.layers], dim=0)
+        Bk = torch.cat([l.cross_attn_image.in_proj_bias[D:2 * D] for l in self.layers], dim=0)
+        Wv = torch.cat([l.cross_attn_image.in_proj_weight[2 * D:] for l in self.layers], dim=0)
+        Bv = torch.cat([l.cross_attn_image.in_proj_bias[2 * D:] for l in self.layers], dim=0)
+        kc = ops.split_cols(ops.linear(mem_pos, Wk, Bk), nl)
+        vv = ops.split_cols(ops.linear(memory, Wv, Bv), nl)
+        out = torch.zeros(T, self.d_model, device=memory.device)
         qpos_time = ops.add_const(query_pos, time_pos)                                       # query_pos + time :602
         inter, ws = [], []
-        for layer in self.layers:
-            out, w = layer.run(out, mem2d, mem_pos2d, n, kpm, query_pos, qpos_time)
+        for i, layer in enumerate(self.layers):
+            out, w = layer.run(out, kc[i], vv[i], kpm, query_pos, qpos_time)
             inter.append(_ln(self.norm, out))
             ws.append(w)
         return torch.stack(inter), torch.stack(ws)
@@ -387,11 +402,9 @@ class QueryDecoder(nn.Module):
         pos_query, temp_query = self.template_generator.run(frames_cls, video_cls)          # :97-99
         anchor = ops.sigmoid(pos_query)                                                      # :101
         time_embed = self.time_embed(T)[:, 0, :]                                             # :120
-        mem2d = memory.reshape(n * S, d)
-        pos2d = mem_pos.reshape(n * S, d)
-        hs, ref = self.decoder.run(mem2d, n, mem_kpm, pos2d, anchor, time_embed)
-        mem_pos2d = ops.add_const(mem2d, pos2d)                                              # memory + pos  :636
-        time_hs, weights = self.temp_decoder.run(mem2d, mem_pos2d, n, mem_kpm, temp_query.contiguous(), time_embed)
+        hs, ref = self.decoder.run(memory, mem_kpm, mem_pos, anchor, time_embed)
+        mem_plus_pos = ops.add_const(memory, mem_pos)                                        # memory + pos  :636
+        time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(), time_embed)
         return hs, ref, time_hs, weights, pos_query
 
     def forward(self, memory_cache, vis_pos=None, text_cls=None):

@@ -29,7 +29,52 @@ def _empty(like: torch.Tensor, *shape) -> torch.Tensor:
     return torch.empty(shape, device=like.device, dtype=_f32)
 
 
+class ZeroArena:
+    """One flat, pre-zeroed fp32 buffer that serves every zero-initialised temporary of a step (weight-gradient
+    accumulators of the split-K wgrad kernels, bias / LayerNorm gradient sums): a single memset per step replaces
+    ~800 tiny fill launches.  `reset()` must be called once per step before the first backward op."""
+
+    def __init__(self, device, numel: int):
+        self.buf = torch.zeros(numel, device=device, dtype=_f32)
+        self.off = 0
+        self.high = 0
+
+    def reset(self):
+        if self.off:
+            self.buf[: self.off].zero_()
+        self.high = max(self.high, self.off)
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        start = (self.off + 63) & ~63  # 256-byte alignment
+        if start + n > self.buf.numel():
+            return None
+        self.off = start + n
+        return self.buf[start:start + n].view(*shape)
+
+
+_ARENA = {}
+
+
+def enable_zero_arena(device, numel: int) -> ZeroArena:
+    a = ZeroArena(device, numel)
+    _ARENA[str(device)] = a
+    return a
+
+
+def disable_zero_arena():
+    _ARENA.clear()
+
+
 def _zeros(like: torch.Tensor, *shape) -> torch.Tensor:
+    a = _ARENA.get(str(like.device))
+    if a is not None:
+        t = a.take(shape)
+        if t is not None:
+            return t
     return torch.zeros(shape, device=like.device, dtype=_f32)
 
 
@@ -439,13 +484,15 @@ class AttnQ1Fn(Function):
     def forward(ctx, q1, q2, k1, k2, v, kpm, scale):
         B, S, D = v.shape
         H = D // 32
-        q1, q2, k1, k2, v = _c(q1), _c(q2), _c(k1), _c(k2), _c(v)
+        q1, q2 = _c(q1), _c(q2)
         _chk(q1, q2, k1, k2, v)
+        ldk, ldv = _ld3(k1), _ld3(v)  # k/v may be column slices of a wider (layer-batched) projection
+        assert k2 is None or _ld3(k2) == ldk
         kp = _c(kpm.to(torch.uint8)) if kpm is not None else None
         out = _empty(v, B, D)
         P = _empty(v, B, H, S)
         L.call("stcat_attn_q1_fwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), L._ptr(kp),
-               out.data_ptr(), P.data_ptr(), B, H, S, D, D, D, scale, L.stream_of(v))
+               out.data_ptr(), P.data_ptr(), B, H, S, D, ldk, ldv, scale, L.stream_of(v))
         ctx.save_for_backward(q1, q2, k1, k2, v, P)
         ctx.scale = scale
         return out
@@ -458,13 +505,36 @@ class AttnQ1Fn(Function):
         g = _c(g)
         dq1 = torch.empty_like(q1)
         dq2 = torch.empty_like(q2) if q2 is not None else None
-        dk1 = torch.empty_like(k1)
-        dk2 = torch.empty_like(k2) if k2 is not None else None
-        dv = torch.empty_like(v)
+        dk1 = _empty(v, B, S, D)
+        dk2 = _empty(v, B, S, D) if k2 is not None else None
+        dv = _empty(v, B, S, D)
         L.call("stcat_attn_q1_bwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), P.data_ptr(),
-               g.data_ptr(), dq1.data_ptr(), L._ptr(dq2), dk1.data_ptr(), L._ptr(dk2), dv.data_ptr(), B, H, S, D, D, D,
-               ctx.scale, L.stream_of(v))
+               g.data_ptr(), dq1.data_ptr(), L._ptr(dq2), dk1.data_ptr(), L._ptr(dk2), dv.data_ptr(), B, H, S, D,
+               _ld3(k1), _ld3(v), ctx.scale, L.stream_of(v))
         return dq1, dq2, dk1, dk2, dv, None, None
+
+
+class SplitColsFn(Function):
+    """[M, n*D] -> n column blocks [M, D] (strided views).  Used to run the K/V projections of all decoder
+    layers as ONE GEMM on the shared memory tensor; the backward concatenates the per-layer gradients so the
+    batched GEMM also has a single dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        D = x.shape[-1] // n
+        ctx.n, ctx.D = n, D
+        ctx.like = x
+        return tuple(x[..., i * D:(i + 1) * D] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x = ctx.like
+        cols = [g if g is not None else torch.zeros(*x.shape[:-1], ctx.D, device=x.device, dtype=x.dtype) for g in gs]
+        return torch.cat(cols, dim=-1), None
+
+
+def split_cols(x, n):
+    return SplitColsFn.apply(x, n)
 
 
 def attn_q1(q1, q2, k1, k2, v, kpm, scale):

@@ -53,6 +53,7 @@ def _worker(rank, world, port, q):
         model(x).square().sum().backward()
         red.finish()
         res.append({n: p.grad.clone().numpy() for n, p in live_trainable(model.named_parameters())})
+        assert model.conv.weight.grad.data_ptr() != 0
         assert model.conv.weight.grad.stride() == model.conv.weight.stride()  # channels_last view kept
     q.put((rank, res, red.message_bytes))
     dist.barrier()
