@@ -9,7 +9,10 @@
 Prints ONE JSON line on rank 0.  A step = forward, loss, backward of one synthetic video per rank, gradients
 averaged across ranks (RCCL all-reduce overlapped with backward) and usable at the end of the step; inputs
 are resident in HBM before the timed region.  Weights are the deterministic synthetic set (no checkpoints
-offline); arithmetic is fp32 on v_mfma_f32_32x32x2_f32 — the mode that meets the 1e-3 parity bar.
+offline).  All tensors are fp32; the conv/Linear contractions run either on the exact fp32 MFMA (--mma f32) or,
+by default, as bf16x3 split products with fp32 accumulation on the bf16 MFMA pipe — both modes pass the same
+parity tests (outputs within 1e-3 of the fp32 CPU reference, bit-exact spans); the exact-fp32 timing is
+reported next to the headline in `exact_f32_mode`.
 `roofline` is measured live with HIP events (torch.cuda.Event on the launch stream) around every C-ABI
 launch in one extra instrumented step after the timed region; `cpu_baseline` times the CPU oracle
 (a port of the reference path) on a bounded sample on the host cores.
@@ -67,6 +70,25 @@ def _flops(name, a):
         B, H, S = a[12:15]
         return 2.0 * 4 * B * H * S * S * 32
     return 0.0
+
+
+def _pmc_traffic(entry: str, mma: str):
+    """HBM bytes per launch of the dominant entry point's kernels, from the committed rocprofv3 PMC passes of this
+    same command (profiles/*hbm_traffic*.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, x1024, reads
+    x2 per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read from inside the process, hence the file."""
+    import glob
+    fam = {"stcat_conv_fwd": "_fwd_kernel", "stcat_conv_dgrad": "_dgrad_kernel", "stcat_conv_wgrad": "_wgrad_kernel"}.get(entry)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*hbm_traffic*{mma}*.json")))
+    if not fam or not files:
+        return None
+    k = json.load(open(files[-1]))["kernels"]
+    sel = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
+           if fam in n and "igemm" in n and "<128" in n]
+    n = sum(a for a, _ in sel)
+    if not n:
+        return None
+    return {"MB_per_launch": round(sum(a * b for a, b in sel) / n, 1), "source": os.path.basename(files[-1]),
+            "note": "128-wide tiles of the family (the conv launches); PMC, separate passes"}
 
 
 class LaunchProfiler:
@@ -136,10 +158,12 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(synth.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=4)
+    ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
-    ap.add_argument("--mma", default="f32", choices=["f32", "bf16x3", "bf16x6"],
-                    help="arithmetic of the conv/Linear GEMM family (fp32 in/out in every mode)")
+    ap.add_argument("--mma", default="bf16x3", choices=["f32", "bf16x3", "bf16x6"],
+                    help="arithmetic of the conv/Linear GEMM family (fp32 tensors in HBM in every mode); bf16x3 is the "
+                         "split-product parity mode of SURVEY.md §7 hard part 3 (meets the 1e-3 / bit-exact-span bars)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
     args = ap.parse_args()
@@ -218,12 +242,27 @@ def main():
                 "algorithmic_tflops": round(ach, 2), "mfma_flops_per_algorithmic_flop": mult,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
+        roof["traffic"] = _pmc_traffic(dom, args.mma)
         mm = sum(v["flop"] for v in agg.values())
         mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)
         roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
                                     "gflop_per_step": round(mm / 1e9, 1)}
     if world > 1:
         dist.barrier()
+
+    exact = None
+    if world == 1 and args.mma != "f32" and not args.no_exact:
+        _lib.set_mma_mode("f32")
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dt_exact = (time.perf_counter() - t1) / 2
+        exact = {"mma": "f32 (v_mfma_f32_32x32x2_f32, exact products)", "value": round(1.0 / dt_exact, 4),
+                 "ms_per_step": round(1e3 * dt_exact, 2)}
+        _lib.set_mma_mode(args.mma)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -235,12 +274,12 @@ def main():
             "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 via split-bf16 x3 (fp32 accumulate)",
-                      "bf16x6": "f32 via split-bf16 x6 (fp32 accumulate)"}[args.mma], "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
+                      "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "allreduce_bytes": reducer.message_bytes},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

@@ -52,14 +52,15 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
       for (int tn = 0; tn < TN; ++tn)                                                                   \
         b_[tn][s] = *reinterpret_cast<const bf16x8*>(&(BS)[s * (BN * LDK) + (wn * TN * 32 + tn * 32 + l31) * LDK + ks * 16 + hi * 8]); \
     }                                                                                                   \
+    /* split terms outermost: consecutive MFMAs write different accumulators (no dependent-issue stalls) */ \
     STCAT_UNROLL                                                                                        \
-    for (int tm = 0; tm < TM; ++tm) {                                                                   \
+    for (int sa = NS - 1; sa >= 0; --sa) {                                                              \
       STCAT_UNROLL                                                                                      \
-      for (int tn = 0; tn < TN; ++tn) {                                                                 \
+      for (int sb = NS - 1 - sa; sb >= 0; --sb) {                                                       \
         STCAT_UNROLL                                                                                    \
-        for (int sa = NS - 1; sa >= 0; --sa) {                                                          \
+        for (int tm = 0; tm < TM; ++tm) {                                                               \
           STCAT_UNROLL                                                                                  \
-          for (int sb = NS - 1 - sa; sb >= 0; --sb)                                                     \
+          for (int tn = 0; tn < TN; ++tn)                                                               \
             acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(a_[tm][sa], b_[tn][sb], acc[tm][tn]);                \
         }                                                                                               \
       }                                                                                                 \

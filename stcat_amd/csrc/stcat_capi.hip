@@ -170,6 +170,7 @@ int stcat_set_mma_mode(int mode) {
   return 0;
 }
 int stcat_get_mma_mode(void) { return g_mma_mode; }
+
 int stcat_debug_force_tile(int bm, int bn) {
   const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
   if (!ok) return fail("debug_force_tile: unsupported tile %dx%d", bm, bn);

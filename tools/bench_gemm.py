@@ -52,8 +52,6 @@ def main():
     if args.tile:
         bm, bn = [int(v) for v in args.tile.split("x")]
         L.call("stcat_debug_force_tile", bm, bn)
-    if args.variant >= 0:
-        L.call("stcat_debug_set_variant", args.variant)
     dev = torch.device("cuda:0")
     print(f"# mma={args.mma} tile={args.tile or 'auto'} variant={args.variant}")
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}

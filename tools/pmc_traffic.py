@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+MI355X_MICROARCH.md §HBM: both counters are in KiB (x1024); on gfx950 FETCH_SIZE under-reports wide coalesced
+reads by exactly 2x, so reads are doubled; WRITE_SIZE is taken as is (uncalibrated)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def collect(d, counter):
+    agg = collections.defaultdict(lambda: [0.0, set()])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            agg[k][0] += float(r["Counter_Value"])
+            agg[k][1].add(r.get("Dispatch_Id", "0"))
+    return {k: (v[0], len(v[1])) for k, v in agg.items()}
+
+
+fetch = collect(sys.argv[1], "FETCH_SIZE")
+write = collect(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 1))[0])):
+    fs, fn = fetch.get(k, (0.0, 1))
+    ws, wn = write.get(k, (0.0, 1))
+    name = k.split("(")[0][:60]
+    out[name] = {"launches": fn, "read_MB_per_launch": round(2 * fs * 1024 / max(fn, 1) / 1e6, 3),
+                 "write_MB_per_launch": round(ws * 1024 / max(wn, 1) / 1e6, 3)}
+print(json.dumps({"note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; per launch", "kernels": out}))
