@@ -48,7 +48,7 @@ def _flops(name, a):
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin
     if name == "stcat_conv_dgrad":
-        n, H, W, Cin, Cout, KH, KW, stride, pad = a[4:13]
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[8:17]
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin  # algorithmic MACs of the transposed conv
     if name == "stcat_conv_wgrad":

@@ -51,9 +51,14 @@ int stcat_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, voi
 int stcat_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* res,
                    float* y, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    int relu, void* stream);
-/* dx = conv_transpose(g, w) (+ add): g NHWC [n,OH,OW,Cout] -> dx NHWC [n,H,W,Cin]  (autograd of conv2d) */
-int stcat_conv_dgrad(const float* g, const float* w, const float* add, float* dx, int n, int H, int W, int Cin,
-                     int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* dx = conv_transpose(g, w) (+ add): g NHWC [n,OH,OW,Cout] -> dx NHWC [n,H,W,Cin]  (autograd of conv2d).
+ * With mask_y (the [n,H,W,Cin] output of the conv+FrozenBN+ReLU that produced this conv's input) the epilogue
+ * also applies that layer's backward: dx = (y > 0 ? dx : 0) * mask_scale[c]  (mask_scale may be NULL).
+ * dx2 (optional, with dx2_scale[c]) receives dx * dx2_scale: at a bottleneck boundary dx is the identity-path
+ * gradient of the block below and dx2 its conv3 upstream gradient. */
+int stcat_conv_dgrad(const float* g, const float* w, const float* add, const float* mask_y, const float* mask_scale,
+                     float* dx, float* dx2, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream);
 /* dw (OHWI, caller-zeroed) += sum over pixels g (x) gathered x  (autograd of conv2d w.r.t. weight) */
 int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, int W, int Cin, int Cout, int KH,
                      int KW, int stride, int pad, void* stream);

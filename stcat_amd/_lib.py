@@ -23,7 +23,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_stem_fwd": "pppppiiis",
     "stcat_maxpool3x3s2": "ppiiiis",
     "stcat_conv_fwd": "ppppppiiiiiiiiiis",
-    "stcat_conv_dgrad": "ppppiiiiiiiiis",
+    "stcat_conv_dgrad": "ppppppppiiiiiiiiis",
     "stcat_conv_wgrad": "pppiiiiiiiiis",
     "stcat_act_bwd": "ppppplii" + "s",
     "stcat_pos_sine_2d": "pppiiis",

@@ -128,35 +128,37 @@ class _BackboneFn(Function):
             x = y
         ctx.tape = tape
         ctx.body = body
-        ctx.first_trainable = tape[0][0] if tape else None
         return x
 
     @staticmethod
     def backward(ctx, dy):
         grads = {}
-        dy = dy.contiguous()
-        for (blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd)) in reversed(ctx.tape):
-            need_dx = blk is not ctx.first_trainable  # below the first trainable block everything is frozen
-            g3, didt = ops.act_bwd_raw(dy, y, s3, want_g=True, want_res=need_dx, relu=True)
+        tape = ctx.tape
+        blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
+        # top of the stack: dz = dy * [y > 0] (identity-path gradient), g3 = dz * scale3 (conv3 upstream)
+        g3, dz = ops.act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
+        for idx in range(len(tape) - 1, -1, -1):
+            blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd) = tape[idx]
+            need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
             grads[id(blk.conv3.weight)] = ops.conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
-            do2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0)
-            g2, _ = ops.act_bwd_raw(do2, o2, s2, want_g=True, relu=True)
+            # each dgrad epilogue applies the ReLU+BN backward of the layer below (no intermediate dO tensor)
+            g2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0, mask_y=o2, mask_scale=s2)
             grads[id(blk.conv2.weight)] = ops.conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
-            do1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1)
-            g1, _ = ops.act_bwd_raw(do1, o1, s1, want_g=True, relu=True)
+            g1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1, mask_y=o1, mask_scale=s1)
             grads[id(blk.conv1.weight)] = ops.conv_wgrad_raw(g1, x, w1.shape, 1, 0)
             gd = None
             if wd is not None:
-                gd, _ = ops.act_bwd_raw(dy, y, sd, want_g=True, relu=True)  # dz * scale_ds
+                gd, _ = ops.act_bwd_raw(dz, None, sd, want_g=True, relu=False)  # dz * scale_downsample
                 grads[id(blk.downsample[0].weight)] = ops.conv_wgrad_raw(gd, x, wd.shape, blk.stride, 0)
             if not need_dx:
                 break
+            # block boundary: x is the ReLU output of the block below; its dz / g3 come out of this epilogue
+            s3_below = tape[idx - 1][6][2]
             if wd is not None:
-                dx = ops.conv_dgrad_raw(gd, wd, x.shape, blk.stride, 0)
-                dx = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dx, out=dx)
+                part = ops.conv_dgrad_raw(gd, wd, x.shape, blk.stride, 0)
+                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=part, out=part, mask_y=x, scale2=s3_below)
             else:
-                dx = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=didt)
-            dy = dx
+                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dz, mask_y=x, scale2=s3_below)
         out = []
         for w in ctx.body.parameters():  # same order as the *weights passed to forward
             g = grads.get(id(w))

@@ -33,6 +33,10 @@ struct IgemmParams {
   const float* scale;  // per output column (FrozenBN scale) or null
   const float* bias;   // per output column or null
   const float* res;    // residual [M][ldr] or null
+  const float* mask;   // dgrad only: activation y [M][ldc] of the producing conv — output is zeroed where y <= 0 ...
+  const float* mscale; // ... and multiplied by that conv's FrozenBN scale[n] (fused ReLU+BN backward), or null
+  float* C2;           // dgrad only: optional second output C2 = C * c2scale[n] (dz and dz*scale of a block boundary)
+  const float* c2scale;
   int M, N, K;
   int ldb, ldc, ldr;
   int c_group, c_group_stride;  // output row m -> (m / c_group) * c_group_stride + (m % c_group) * ldc
@@ -296,6 +300,7 @@ __global__ void __launch_bounds__(256) igemm_dgrad_kernel(IgemmParams p) {
   STCAT_UNROLL
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn * TN * 32 + tn * 32 + l31;
+    const float msc = p.mscale ? p.mscale[n] : 1.f;
     STCAT_UNROLL
     for (int tm = 0; tm < TM; ++tm) {
       STCAT_UNROLL
@@ -304,7 +309,9 @@ __global__ void __launch_bounds__(256) igemm_dgrad_kernel(IgemmParams p) {
         if (m < p.M) {
           float val = tot[tm][tn][r];
           if (p.res) val += p.res[(long)m * p.ldr + n];  // fused gradient accumulation
+          if (p.mask) val = p.mask[(long)m * p.ldc + n] > 0.f ? val * msc : 0.f;
           p.C[(long)m * p.ldc + n] = val;
+          if (p.C2) p.C2[(long)m * p.ldc + n] = val * p.c2scale[n];
         }
       }
     }

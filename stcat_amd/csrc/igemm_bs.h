@@ -157,10 +157,29 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
     __syncthreads();                                                                                     \
   }
 
+// Epilogue through LDS: the wave-private MFMA accumulators (lane = column, register = row) are written to a
+// padded fp32 tile, then every thread handles whole float4 row segments, so scale/bias/residual/mask reads
+// and the output stores are 16-byte, 512-byte-coalesced accesses instead of 64 dword accesses per lane.
+#define STCAT_BS_ACC_TO_LDS                                                                              \
+  STCAT_UNROLL                                                                                           \
+  for (int tn = 0; tn < TN; ++tn) {                                                                      \
+    STCAT_UNROLL                                                                                         \
+    for (int tm = 0; tm < TM; ++tm) {                                                                    \
+      STCAT_UNROLL                                                                                       \
+      for (int r = 0; r < 16; ++r)                                                                       \
+        Cs[(wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDC + wn * TN * 32 + tn * 32 + l31] = acc[tm][tn][r]; \
+    }                                                                                                    \
+  }                                                                                                      \
+  __syncthreads();
+
 #define STCAT_BS_PROLOGUE                                                                                \
   constexpr int BK = 32, LDK = STCAT_BS_LDK, TM = BM / 64, TN = BN / 64;                                 \
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][NS * BM * LDK];                                   \
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][NS * BN * LDK];                                   \
+  constexpr int A_ELEMS = NS * BM * LDK, B_ELEMS = NS * BN * LDK, LDC = BN + 4;                          \
+  constexpr int SMEM_BYTES = (2 * (A_ELEMS + B_ELEMS) * 2 > BM * LDC * 4) ? 2 * (A_ELEMS + B_ELEMS) * 2 : BM * LDC * 4; \
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];                                     \
+  __bf16 (*As)[A_ELEMS] = reinterpret_cast<__bf16 (*)[A_ELEMS]>(smem_raw);                               \
+  __bf16 (*Bs)[B_ELEMS] = reinterpret_cast<__bf16 (*)[B_ELEMS]>(smem_raw + 2 * A_ELEMS * 2);             \
+  float* Cs = reinterpret_cast<float*>(smem_raw); /* epilogue: the fp32 output tile, rows padded to LDC */ \
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;                                               \
   const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;                              \
   const int num_n = p.N / BN;                                                                            \
@@ -192,23 +211,28 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   STCAT_BS_PIPELINE(STCAT_BSF_LOAD, STCAT_BSF_STORE)
 #undef STCAT_BSF_LOAD
 #undef STCAT_BSF_STORE
+  STCAT_BS_ACC_TO_LDS
+  constexpr int F4 = BN / 4;
   STCAT_UNROLL
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
-    STCAT_UNROLL
-    for (int tm = 0; tm < TM; ++tm) {
-      STCAT_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m < p.M) {
-          float val = acc[tm][tn][r] * sc + bi;
-          if (p.res) val += p.res[(long)m * p.ldr + n];
-          if (p.relu) val = fmaxf(val, 0.f);
-          p.C[(long)m * p.ldc + n] = val;
-        }
+  for (int j = 0; j < BM * F4 / 256; ++j) {
+    const int i = t + 256 * j, row = i / F4, c4 = i - row * F4;
+    const int m = m0 + row, n = n0 + c4 * 4;
+    if (m < p.M) {
+      float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
+      if (p.scale) {
+        const float4 sc = stcat_ld4(p.scale + n);
+        v4.x *= sc.x; v4.y *= sc.y; v4.z *= sc.z; v4.w *= sc.w;
       }
+      if (p.bias) {
+        const float4 bi = stcat_ld4(p.bias + n);
+        v4.x += bi.x; v4.y += bi.y; v4.z += bi.z; v4.w += bi.w;
+      }
+      if (p.res) {
+        const float4 rr = stcat_ld4(p.res + (long)m * p.ldr + n);
+        v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;
+      }
+      if (p.relu) { v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f); }
+      stcat_st4(p.C + (long)m * p.ldc + n, v4);
     }
   }
 }
@@ -248,19 +272,29 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
   STCAT_BS_PIPELINE(STCAT_BSD_LOAD, STCAT_BSD_STORE)
 #undef STCAT_BSD_LOAD
 #undef STCAT_BSD_STORE
+  STCAT_BS_ACC_TO_LDS
+  constexpr int F4 = BN / 4;
   STCAT_UNROLL
-  for (int tn = 0; tn < TN; ++tn) {
-    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
-    STCAT_UNROLL
-    for (int tm = 0; tm < TM; ++tm) {
-      STCAT_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m < p.M) {
-          float val = acc[tm][tn][r];
-          if (p.res) val += p.res[(long)m * p.ldr + n];
-          p.C[(long)m * p.ldc + n] = val;
-        }
+  for (int j = 0; j < BM * F4 / 256; ++j) {
+    const int i = t + 256 * j, row = i / F4, c4 = i - row * F4;
+    const int m = m0 + row, n = n0 + c4 * 4;
+    if (m < p.M) {
+      float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
+      if (p.res) {
+        const float4 rr = stcat_ld4(p.res + (long)m * p.ldr + n);
+        v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;
+      }
+      if (p.mask) {  // fused ReLU+BN backward of the layer below
+        const float4 mk = stcat_ld4(p.mask + (long)m * p.ldc + n);
+        float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.mscale) ms = stcat_ld4(p.mscale + n);
+        v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;
+        v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;
+      }
+      stcat_st4(p.C + (long)m * p.ldc + n, v4);
+      if (p.C2) {
+        const float4 s2 = stcat_ld4(p.c2scale + n);
+        stcat_st4(p.C2 + (long)m * p.ldc + n, make_float4(v4.x * s2.x, v4.y * s2.y, v4.z * s2.z, v4.w * s2.w));
       }
     }
   }

@@ -225,13 +225,15 @@ int stcat_conv_fwd(const float* x, const float* w, const float* scale, const flo
   return launch_fwd(p, (hipStream_t)stream);
 }
 
-int stcat_conv_dgrad(const float* g, const float* w, const float* add, float* dx, int n, int H, int W, int Cin,
-                     int Cout, int KH, int KW, int stride, int pad, void* stream) {
+int stcat_conv_dgrad(const float* g, const float* w, const float* add, const float* mask_y, const float* mask_scale,
+                     float* dx, float* dx2, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
+                     int KW, int stride, int pad, void* stream) {
+  if ((dx2 != nullptr) != (dx2_scale != nullptr)) return fail("conv_dgrad: dx2 and dx2_scale go together");
   if (Cout % 16 != 0 || Cin % 64 != 0) return fail("conv_dgrad: need Cout %% 16 == 0 and Cin %% 64 == 0 (%d, %d)", Cout, Cin);
   if (!aligned16(g) || !aligned16(w)) return fail("conv_dgrad: operands must be 16-byte aligned");
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   IgemmParams p = {};
-  p.A = g; p.B = w; p.C = dx; p.res = add;
+  p.A = g; p.B = w; p.C = dx; p.res = add; p.mask = mask_y; p.mscale = mask_scale; p.C2 = dx2; p.c2scale = dx2_scale;
   p.a_bytes = bytes_of((long)n * OH * OW * Cout); p.b_bytes = bytes_of((long)Cout * KH * KW * Cin);
   p.M = n * H * W; p.N = Cin; p.K = KH * KW * Cout; p.ldb = KH * KW * Cin; p.ldc = Cin; p.ldr = Cin;
   p.c_group = p.M; p.relu = 0;

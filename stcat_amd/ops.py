@@ -558,13 +558,17 @@ def conv_fwd_raw(x, w_ohwi, scale, bias, res, stride, pad, relu):
     return y
 
 
-def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None):
+def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None, mask_y=None, mask_scale=None,
+                   scale2=None):
+    """mask_y / mask_scale: fuse the ReLU+FrozenBN backward of the layer that produced this conv's input.
+    scale2: also return dx * scale2[c] as a second tensor (block-boundary form)."""
     n, H, W, Cin = in_shape
     Cout, KH, KW, _ = w_ohwi.shape
     dx = _empty(g, n, H, W, Cin) if out is None else out
-    L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), dx.data_ptr(), n, H, W, Cin, Cout, KH, KW,
-           stride, pad, L.stream_of(g))
-    return dx
+    dx2 = _empty(g, n, H, W, Cin) if scale2 is not None else None
+    L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), L._ptr(mask_y), L._ptr(mask_scale),
+           dx.data_ptr(), L._ptr(dx2), L._ptr(scale2), n, H, W, Cin, Cout, KH, KW, stride, pad, L.stream_of(g))
+    return dx if scale2 is None else (dx, dx2)
 
 
 def conv_wgrad_raw(g, x, w_shape_ohwi, stride, pad):

@@ -110,12 +110,21 @@ def _conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=None):
         dx = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad)
         dw = ops.conv_wgrad_raw(G, xd, wd.shape, stride, pad)
         dx2 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, add=dx.clone())
+        ymask = torch.randn_like(xd)
+        msc = torch.rand(xd.shape[-1], device=dev) + 0.5
+        dx3 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, mask_y=ymask, mask_scale=msc)
+        dx4, dx5 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, add=dx.clone(), mask_y=ymask, scale2=msc)
     finally:
         L.call("stcat_debug_force_tile", 0, 0)
     tag = f"conv {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
     close(y.permute(0, 3, 1, 2), ref, TOL, tag + " fwd")
     close(dx.permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
     close(dx2.permute(0, 3, 1, 2), 2 * xr.grad, TOL, tag + " dgrad+add")
+    ref3 = xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0) * msc.cpu()
+    close(dx3, ref3, TOL, tag + " dgrad+fused relu/bn backward")
+    ref4 = 2 * xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0)
+    close(dx4, ref4, TOL, tag + " dgrad boundary dz")
+    close(dx5, ref4 * msc.cpu(), TOL, tag + " dgrad boundary dz*scale")
     close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
     if res:
         mask = (ref > 0).float() if relu else torch.ones_like(ref)
