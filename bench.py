@@ -196,12 +196,16 @@ def main():
     act, tb = synth.synth_targets(T, seed=rank)
     targets = [{"actioness": act.to(dev), "boxs": BoxList(tb).to(dev)}]
 
+    # target-derived index/mask tensors belong to the input pipeline (they depend on the annotations only)
+    plan = criterion.plan(targets, [T], dev)
+    uniform_w = len({wd[k] for k in wd if k.startswith("loss_bbox")}) == 1  # aux copies share the main weights
+
     def step():
         reducer.zero_grad()
         arena.reset()
         out = model(videos, ["synthetic"])
-        losses = criterion(out, targets, [T])
-        total = sum(losses[k] * wd[k] for k in losses)
+        losses = criterion(out, targets, [T], plan=plan)
+        total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
         total.backward()
         reducer.finish()
         return total

@@ -107,8 +107,50 @@ def paired_giou(a, b):
     return inter / union - (hull - union) / hull
 
 
+class LossPlan:
+    """Everything VideoSTGLoss derives from the targets alone (GT span, box rows, masks, Gaussian span targets,
+    actioness weights), built once per batch on the host side of the input pipeline — the reference recomputes
+    it inside the loss with device->host syncs (criterion.py:160-192), which stalls the launch queue."""
+
+    def __init__(self, targets, durations, device, sigma: float, eos_coef: float):
+        T = max(durations)
+        b = len(durations)
+        self.T, self.b = T, b
+        bounds, rows = [], []
+        for i, tgt in enumerate(targets):
+            on = torch.where(tgt["actioness"].cpu())[0].tolist()
+            bounds.append((on[0], on[-1]))
+            rows.extend(range(i * T + on[0], i * T + on[-1] + 1))
+        self.bounds = bounds
+        self.rows = torch.tensor(rows, dtype=torch.long).to(device, non_blocking=True)
+        self.num_boxes_local = float(sum(len(t["boxs"]) for t in targets))
+        time_mask = torch.zeros(b, T, dtype=torch.bool)
+        positive = torch.zeros(b, T, dtype=torch.bool)
+        weight = torch.full((b, T), eos_coef)
+        for i, d in enumerate(durations):
+            time_mask[i, :d] = True
+            positive[i, bounds[i][0]:bounds[i][1] + 1] = True
+            weight[i, bounds[i][0]:bounds[i][1] + 1] = 1
+        grid = torch.arange(T)[None, :]
+        dists = []
+        for idx in (0, 1):
+            tgt_idx = torch.tensor([bd[idx] for bd in bounds], dtype=torch.long)
+            d_ = (-((grid - tgt_idx[:, None]) ** 2) / (2 * sigma ** 2)).exp()
+            dists.append(F.normalize(d_ + 1e-6, p=1, dim=1))
+        pos_or_pad = positive | (~time_mask)
+        self.time_mask = time_mask.to(device)
+        self.time_mask_f = time_mask.float().to(device)
+        self.pos_or_pad = pos_or_pad.to(device)
+        self.nb_neg = ((~pos_or_pad).sum(1) + 1e-6).to(device)
+        self.act_weight = weight.to(device)
+        self.dist = torch.stack(dists, dim=-1).to(device)                       # [b,T,2]
+        self.tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).to(device)
+        self.actioness = torch.stack([t["actioness"] for t in targets]).float().to(device)
+
+
 class VideoSTGLoss(nn.Module):
-    """Same constructor / forward contract as models/criterion.py:11-208."""
+    """Same constructor / forward contract as models/criterion.py:11-208.  All decoder layers (main + aux) are
+    evaluated in ONE vectorised pass over stacked [layers, ...] tensors instead of 6 x ~15 small ops."""
 
     def __init__(self, cfg=None, losses: Sequence[str] = ("boxes", "sted", "guided_attn", "actioness"),
                  sigma: float = 2.0, eos_coef: float = 0.3):
@@ -117,70 +159,63 @@ class VideoSTGLoss(nn.Module):
         self.sigma = sigma if cfg is None else cfg.SOLVER.SIGMA
         self.eos_coef = eos_coef if cfg is None else cfg.SOLVER.EOS_COEF
 
-    def _layer_losses(self, out, tgt_boxes, actioness, bounds, num_boxes, time_mask, positive):
-        res = {}
-        dev = time_mask.device
-        T = time_mask.shape[1]
-        if "boxes" in self.losses:
-            src = out["pred_boxes"]
-            res["loss_bbox"] = F.l1_loss(src, tgt_boxes, reduction="none").sum() / max(num_boxes, 1)
-            res["loss_giou"] = (1 - paired_giou(box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt_boxes))).sum() \
-                / max(num_boxes, 1)
-        if "sted" in self.losses:
-            sted = out["pred_sted"].masked_fill(~time_mask[:, :, None], -1e32)
-            grid = torch.arange(T, device=dev)[None, :]
-            total = 0
-            for col, idx in ((0, 0), (1, 1)):
-                tgt = torch.tensor([b[idx] for b in bounds], dtype=torch.long, device=dev)
-                dist = F.normalize((-((grid - tgt[:, None]) ** 2) / (2 * self.sigma ** 2)).exp() + 1e-6, p=1, dim=1)
-                prob = sted[:, :, col].softmax(1)
-                total = total + prob * ((prob + 1e-6) / dist).log() * time_mask
-            res["loss_sted"] = total.mean()
-        if "guided_attn" in self.losses:
-            w = out["weights"]
-            pos = positive | (~time_mask)
-            la = (-(1 - w + 1e-6).log()).masked_fill(pos[:, :, None], 0)
-            nb_neg = (~pos).sum(1) + 1e-6
-            res["loss_guided_attn"] = (la.sum(2) / nb_neg[:, None]).sum(1).mean()
-        if "actioness" in self.losses:
-            pa = out["pred_actioness"].squeeze(-1)
-            weight = torch.full(pa.shape, self.eos_coef, device=dev)
-            for i, (s, e) in enumerate(bounds):
-                weight[i, s:e + 1] = 1
-            la = F.binary_cross_entropy_with_logits(pa, actioness, weight=weight, reduction="none")
-            res["loss_actioness"] = (la * time_mask).mean()
-        return res
+    def plan(self, targets, durations, device) -> LossPlan:
+        return LossPlan(targets, durations, device, self.sigma, self.eos_coef)
 
-    def forward(self, outputs, targets, durations):
-        T = max(durations)
+    def forward(self, outputs, targets, durations, plan: Optional[LossPlan] = None):
         dev = outputs["pred_boxes"].device
-        bounds, rows = [], []
-        for i, tgt in enumerate(targets):
-            on = torch.where(tgt["actioness"])[0].tolist()
-            bounds.append((on[0], on[-1]))
-            rows.extend(range(i * T + on[0], i * T + on[-1] + 1))
-        rows = torch.tensor(rows, dtype=torch.long, device=dev)
-        outputs["pred_boxes"] = outputs["pred_boxes"][rows]                                  # criterion.py:168
-        for aux in outputs.get("aux_outputs", []):
-            aux["pred_boxes"] = aux["pred_boxes"][rows]
-        num_boxes = torch.as_tensor([float(sum(len(t["boxs"]) for t in targets))], device=dev)
-        world = 1
+        if plan is None:
+            plan = targets if isinstance(targets, LossPlan) else self.plan(targets, durations, dev)
+        aux = outputs.get("aux_outputs", [])
+        layers = list(aux) + [outputs]                                              # main output last
+        nl = len(layers)
+        # criterion.py:168-171 — the reference overwrites pred_boxes with the GT-span rows
+        boxes = torch.stack([l["pred_boxes"] for l in layers])[:, plan.rows]        # [nl, nbox, 4]
+        for i, l in enumerate(layers):
+            l["pred_boxes"] = boxes[i]
+        num_boxes = plan.num_boxes_local
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(num_boxes)                                          # criterion.py:175-177
-            world = torch.distributed.get_world_size()
-        num_boxes = torch.clamp(num_boxes / world, min=1).item()
-        time_mask = torch.zeros(len(durations), T, dtype=torch.bool, device=dev)
-        positive = torch.zeros_like(time_mask)
-        for i, d in enumerate(durations):
-            time_mask[i, :d] = True
-            positive[i, bounds[i][0]:bounds[i][1] + 1] = True
-        tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).to(dev)
-        actioness = torch.stack([t["actioness"] for t in targets]).float().to(dev)
-        losses = self._layer_losses(outputs, tgt_boxes, actioness, bounds, num_boxes, time_mask, positive)
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            for k, v in self._layer_losses(aux, tgt_boxes, actioness, bounds, num_boxes, time_mask, positive).items():
-                losses[f"{k}_{i}"] = v
+            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=dev)
+            torch.distributed.all_reduce(nb)                                         # criterion.py:175-177
+            num_boxes = torch.clamp(nb / torch.distributed.get_world_size(), min=1)  # stays on device: no sync
+        else:
+            num_boxes = max(num_boxes, 1.0)
+        vec = {}
+        if "boxes" in self.losses:
+            tgt = plan.tgt_boxes[None].expand(nl, -1, -1)
+            vec["loss_bbox"] = (boxes - tgt).abs().sum((1, 2)) / num_boxes
+            giou = paired_giou(box_cxcywh_to_xyxy(boxes.reshape(-1, 4)), box_cxcywh_to_xyxy(tgt.reshape(-1, 4)))
+            vec["loss_giou"] = (1 - giou).view(nl, -1).sum(1) / num_boxes
+        if "sted" in self.losses:
+            sted = torch.stack([l["pred_sted"] for l in layers])                    # [nl,b,T,2]
+            sted = sted.masked_fill(~plan.time_mask[None, :, :, None], -1e32)
+            prob = sted.softmax(2)
+            kl = prob * ((prob + 1e-6) / plan.dist[None]).log() * plan.time_mask_f[None, :, :, None]
+            vec["loss_sted"] = kl.sum(3).mean((1, 2))
+        if "guided_attn" in self.losses:
+            w = torch.stack([l["weights"] for l in layers])                         # [nl,b,T,T]
+            la = (-(1 - w + 1e-6).log()).masked_fill(plan.pos_or_pad[None, :, :, None], 0)
+            vec["loss_guided_attn"] = (la.sum(3) / plan.nb_neg[None, :, None]).sum(2).mean(1)
+        if "actioness" in self.losses:
+            pa = torch.stack([l["pred_actioness"] for l in layers]).squeeze(-1)     # [nl,b,T]
+            la = F.binary_cross_entropy_with_logits(pa, plan.actioness[None].expand(nl, -1, -1),
+                                                    weight=plan.act_weight[None].expand(nl, -1, -1), reduction="none")
+            vec["loss_actioness"] = (la * plan.time_mask_f[None]).mean((1, 2))
+        losses = {}
+        for k, v in vec.items():
+            losses[k] = v[nl - 1]
+            for i in range(nl - 1):
+                losses[f"{k}_{i}"] = v[i]
+        self._last_vec = vec
         return losses
+
+    def weighted_total(self, weight_dict):
+        """sum_k w_k * loss_k of the last forward, from the per-layer vectors (a handful of ops instead of 30)."""
+        total = 0
+        for k, v in self._last_vec.items():
+            if k in weight_dict:
+                total = total + weight_dict[k] * v.sum()
+        return total
 
 
 class PostProcess(nn.Module):
