@@ -48,7 +48,7 @@ def _flops(name, a):
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin
     if name == "stcat_conv_dgrad":
-        n, H, W, Cin, Cout, KH, KW, stride, pad = a[8:17]
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[9:18]
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin  # algorithmic MACs of the transposed conv
     if name == "stcat_conv_wgrad":
@@ -61,7 +61,7 @@ def _flops(name, a):
     if name == "stcat_linear_fwd":
         return 2.0 * a[5] * a[6] * a[7]
     if name in ("stcat_linear_dgrad", "stcat_linear_wgrad"):
-        o = 4 if name == "stcat_linear_dgrad" else 3
+        o = 5 if name == "stcat_linear_dgrad" else 3
         return 2.0 * a[o] * a[o + 1] * a[o + 2]
     if name == "stcat_mha_self_fwd":
         B, H, S = a[6:9]

@@ -55,10 +55,13 @@ int stcat_conv_fwd(const float* x, const float* w, const float* scale, const flo
  * With mask_y (the [n,H,W,Cin] output of the conv+FrozenBN+ReLU that produced this conv's input) the epilogue
  * also applies that layer's backward: dx = (y > 0 ? dx : 0) * mask_scale[c]  (mask_scale may be NULL).
  * dx2 (optional, with dx2_scale[c]) receives dx * dx2_scale: at a bottleneck boundary dx is the identity-path
- * gradient of the block below and dx2 its conv3 upstream gradient. */
+ * gradient of the block below and dx2 its conv3 upstream gradient.  wt: optional transposed weights (below). */
 int stcat_conv_dgrad(const float* g, const float* w, const float* add, const float* mask_y, const float* mask_scale,
-                     float* dx, float* dx2, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
-                     int KW, int stride, int pad, void* stream);
+                     float* dx, float* dx2, const float* dx2_scale, const float* wt, int n, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* wt = stcat_weight_transpose(w): OHWI [Cout][taps][Cin] -> [taps][Cin][Cout].  When given (and a split-bf16 mode is
+ * active) the data gradient runs on the forward kernel's staging path; NULL keeps the generic path. */
+int stcat_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin, void* stream);
 /* dw (OHWI, caller-zeroed) += sum over pixels g (x) gathered x  (autograd of conv2d w.r.t. weight) */
 int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, int W, int Cin, int Cout, int KH,
                      int KW, int stride, int pad, void* stream);
@@ -81,9 +84,9 @@ int stcat_sine_embed_bwd(const float* anchor, const float* dimt, const float* do
  * (m / c_group)*c_group_stride + (m % c_group)*ldy  (c_group <= 0: plain m*ldy).  N % 64 == 0, K % 16 == 0. */
 int stcat_linear_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
                      int K, int ldx, int ldy, int ldr, int relu, int c_group, long c_group_stride, void* stream);
-/* dx[M,K] = g[M,N] . w[N,K] (+ add[M,K]);  K % 64 == 0, N % 16 == 0 */
-int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
-                       int lddx, void* stream);
+/* dx[M,K] = g[M,N] . w[N,K] (+ add[M,K]);  K % 64 == 0, N % 16 == 0; wt = optional w^T [K][N] (weight_transpose) */
+int stcat_linear_dgrad(const float* g, const float* w, const float* add, const float* wt, float* dx, int M, int N,
+                       int K, int ldg, int lddx, void* stream);
 /* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0 */
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, int K, int ldg, int ldx,
                        void* stream);

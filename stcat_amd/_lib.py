@@ -23,14 +23,15 @@ SIGNATURES: Dict[str, str] = {
     "stcat_stem_fwd": "pppppiiis",
     "stcat_maxpool3x3s2": "ppiiiis",
     "stcat_conv_fwd": "ppppppiiiiiiiiiis",
-    "stcat_conv_dgrad": "ppppppppiiiiiiiiis",
+    "stcat_conv_dgrad": "pppppppppiiiiiiiiis",
+    "stcat_weight_transpose": "ppiiis",
     "stcat_conv_wgrad": "pppiiiiiiiiis",
     "stcat_act_bwd": "ppppplii" + "s",
     "stcat_pos_sine_2d": "pppiiis",
     "stcat_sine_embed_fwd": "pppis",
     "stcat_sine_embed_bwd": "ppppis",
     "stcat_linear_fwd": "pppppiiiiiiiils",
-    "stcat_linear_dgrad": "ppppiiiiis",
+    "stcat_linear_dgrad": "pppppiiiiis",
     "stcat_linear_wgrad": "pppiiiiis",
     "stcat_small_linear_fwd": "ppppiiis",
     "stcat_small_linear_bwd": "ppppppiiis",

@@ -43,6 +43,7 @@ struct IgemmParams {
   int relu;
   int k_chunk;  // wgrad: rows of the M reduction per grid.z slice (multiple of 16)
   unsigned a_bytes, b_bytes;  // extents of A and B for the bounds-checked buffer loads (split-bf16 kernels)
+  unsigned b_tap_stride;      // split-bf16 fwd-path B addressing: byte offset of K-tile = tap*b_tap_stride + c0*4
   IgemmGeom g;
 };
 

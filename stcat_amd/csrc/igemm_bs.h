@@ -204,8 +204,12 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   const int nk = p.K / BK;
 #define STCAT_BSF_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
-  STCAT_UNROLL                                                                                           \
-  for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bufB, b_off[j], (unsigned)(KT) * (BK * 4));
+  {                                                                                                      \
+    const int r0b = (KT) * BK, tapb = r0b / g.C, c0b = r0b - tapb * g.C;                                 \
+    const unsigned soffb = (unsigned)tapb * p.b_tap_stride + (unsigned)c0b * 4;                          \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bufB, b_off[j], soffb);                 \
+  }
 #define STCAT_BSF_STORE(SET, BUF) \
   STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
   STCAT_BS_PIPELINE(STCAT_BSF_LOAD, STCAT_BSF_STORE)
@@ -232,7 +236,18 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
         v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;
       }
       if (p.relu) { v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f); }
+      if (p.mask) {  // dgrad through this kernel (pre-transposed weights): fused ReLU+BN backward of the layer below
+        const float4 mk = stcat_ld4(p.mask + (long)m * p.ldc + n);
+        float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.mscale) ms = stcat_ld4(p.mscale + n);
+        v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;
+        v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;
+      }
       stcat_st4(p.C + (long)m * p.ldc + n, v4);
+      if (p.C2) {
+        const float4 s2 = stcat_ld4(p.c2scale + n);
+        stcat_st4(p.C2 + (long)m * p.ldc + n, make_float4(v4.x * s2.x, v4.y * s2.y, v4.z * s2.z, v4.w * s2.w));
+      }
     }
   }
 }

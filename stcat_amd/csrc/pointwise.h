@@ -346,3 +346,23 @@ __global__ void __launch_bounds__(256) small_linear_dw_kernel(const float* g, co
     if (db && k == 0) db[n] = accb;
   }
 }
+
+// ---------------------------------------------------------------------------------
+// weight transpose for the data-gradient GEMM: W[Cout][taps][Cin] (OHWI / [N][K]) -> Wt[taps][Cin][Cout],
+// so that dgrad's reduction index (tap, co) is contiguous and it can use the forward kernel's staging path.
+// One 32x32 LDS tile per block; ~0.15 ms per step for all 83 M hot-path weights.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weight_transpose_kernel(const float* w, float* wt, int Cout, int taps, int Cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * taps + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wt[((long)tap * Cin + ci) * Cout + co] = tile[tx][r];
+  }
+}

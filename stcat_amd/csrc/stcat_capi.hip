@@ -219,6 +219,7 @@ int stcat_conv_fwd(const float* x, const float* w, const float* scale, const flo
   IgemmParams p = {};
   p.A = x; p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = res;
   p.a_bytes = bytes_of((long)n * H * W * Cin); p.b_bytes = bytes_of((long)Cout * KH * KW * Cin);
+  p.b_tap_stride = (unsigned)Cin * 4;
   p.M = n * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout;
   p.c_group = p.M; p.c_group_stride = 0; p.relu = relu;
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
@@ -226,8 +227,8 @@ int stcat_conv_fwd(const float* x, const float* w, const float* scale, const flo
 }
 
 int stcat_conv_dgrad(const float* g, const float* w, const float* add, const float* mask_y, const float* mask_scale,
-                     float* dx, float* dx2, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
-                     int KW, int stride, int pad, void* stream) {
+                     float* dx, float* dx2, const float* dx2_scale, const float* wt, int n, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, void* stream) {
   if ((dx2 != nullptr) != (dx2_scale != nullptr)) return fail("conv_dgrad: dx2 and dx2_scale go together");
   if (Cout % 16 != 0 || Cin % 64 != 0) return fail("conv_dgrad: need Cout %% 16 == 0 and Cin %% 64 == 0 (%d, %d)", Cout, Cin);
   if (!aligned16(g) || !aligned16(w)) return fail("conv_dgrad: operands must be 16-byte aligned");
@@ -242,6 +243,11 @@ int stcat_conv_dgrad(const float* g, const float* w, const float* add, const flo
   q.H = OH; q.W = OW; q.C = Cout; q.ld = Cout; q.OH = H; q.OW = W; q.KH = KH; q.KW = KW;
   q.mul = 1; q.off = pad; q.sgn = -1; q.div = stride;
   p.g = q;
+  if (wt && g_mma_mode != 0 && bs_ok(p)) {  // transposed weights [tap][Cin][Cout]: the forward kernel's staging path
+    p.B = wt; p.ldb = Cout; p.b_tap_stride = (unsigned)((long)Cin * Cout * 4);
+    p.c_group = p.M;
+    return launch_fwd(p, (hipStream_t)stream);
+  }
   return launch_dgrad(p, (hipStream_t)stream);
 }
 
@@ -255,6 +261,13 @@ int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, in
   p.a_bytes = bytes_of((long)n * OH * OW * Cout); p.b_bytes = bytes_of((long)n * H * W * Cin);
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
   return launch_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
+}
+
+int stcat_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin, void* stream) {
+  if (Cout <= 0 || taps <= 0 || Cin <= 0) return fail("weight_transpose: bad shape");
+  STCAT_LAUNCH(weight_transpose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(256), 0, (hipStream_t)stream, w,
+               wt, Cout, taps, Cin);
+  return launch_status();
 }
 
 int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G, float* dres, long n, int C,
@@ -293,6 +306,7 @@ int stcat_linear_fwd(const float* x, const float* w, const float* bias, const fl
   IgemmParams p = {};
   p.A = x; p.B = w; p.C = y; p.scale = nullptr; p.bias = bias; p.res = res;
   p.a_bytes = bytes_of((long)(M - 1) * ldx + K); p.b_bytes = bytes_of((long)N * K);
+  p.b_tap_stride = (unsigned)K * 4;
   p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = ldy; p.ldr = ldr;
   p.c_group = c_group > 0 ? c_group : M;
   p.c_group_stride = (int)c_group_stride;
@@ -301,8 +315,8 @@ int stcat_linear_fwd(const float* x, const float* w, const float* bias, const fl
   return launch_fwd(p, (hipStream_t)stream);
 }
 
-int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
-                       int lddx, void* stream) {
+int stcat_linear_dgrad(const float* g, const float* w, const float* add, const float* wt, float* dx, int M, int N,
+                       int K, int ldg, int lddx, void* stream) {
   if (K % 64 != 0 || N % 16 != 0) return fail("linear_dgrad: need K %% 64 == 0, N %% 16 == 0 (N=%d K=%d)", N, K);
   if (ldg % 4 != 0 || !aligned16(g) || !aligned16(w)) return fail("linear_dgrad: g/w must be 16-byte aligned rows");
   IgemmParams p = {};
@@ -314,6 +328,10 @@ int stcat_linear_dgrad(const float* g, const float* w, const float* add, float* 
   q.H = 1; q.W = 1; q.C = N; q.ld = ldg; q.OH = 1; q.OW = 1; q.KH = 1; q.KW = 1;
   q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
   p.g = q;
+  if (wt && g_mma_mode != 0 && bs_ok(p)) {  // wt = w^T [K][N]
+    p.B = wt; p.ldb = N; p.b_tap_stride = 0;
+    return launch_fwd(p, (hipStream_t)stream);
+  }
   return launch_dgrad(p, (hipStream_t)stream);
 }
 

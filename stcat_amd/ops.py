@@ -179,7 +179,9 @@ class LinearFn(Function):
         if N % 64 == 0:
             if ctx.needs_input_grad[0]:
                 dx = _empty(g, M, K)
-                L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, dx.data_ptr(), M, N, K, N, K, st)
+                wt = weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
+                L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, L._ptr(wt), dx.data_ptr(), M, N, K, N,
+                       K, st)
             if ctx.needs_input_grad[1]:
                 dw = _zeros(g, N, K)
                 L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), M, N, K, N, K, st)
@@ -566,9 +568,19 @@ def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None, mask_y=
     Cout, KH, KW, _ = w_ohwi.shape
     dx = _empty(g, n, H, W, Cin) if out is None else out
     dx2 = _empty(g, n, H, W, Cin) if scale2 is not None else None
+    wt = weight_transpose(w_ohwi.view(Cout, KH * KW, Cin)) if L.get_mma_mode() != "f32" else None
     L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), L._ptr(mask_y), L._ptr(mask_scale),
-           dx.data_ptr(), L._ptr(dx2), L._ptr(scale2), n, H, W, Cin, Cout, KH, KW, stride, pad, L.stream_of(g))
+           dx.data_ptr(), L._ptr(dx2), L._ptr(scale2), L._ptr(wt), n, H, W, Cin, Cout, KH, KW, stride, pad,
+           L.stream_of(g))
     return dx if scale2 is None else (dx, dx2)
+
+
+def weight_transpose(w3: torch.Tensor) -> torch.Tensor:
+    """W [Cout, taps, Cin] -> [taps, Cin, Cout] (reduction-contiguous operand for the data-gradient GEMM)."""
+    Cout, taps, Cin = w3.shape
+    wt = _empty(w3, taps, Cin, Cout)
+    L.call("stcat_weight_transpose", w3.data_ptr(), wt.data_ptr(), Cout, taps, Cin, L.stream_of(w3))
+    return wt
 
 
 def conv_wgrad_raw(g, x, w_shape_ohwi, stride, pad):
