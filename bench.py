@@ -173,11 +173,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # STCAT_DIST_BACKEND=gloo + several ranks on one GPU is a test configuration for 1-GPU boxes (RCCL itself
+    # refuses duplicate devices); the driver's multi-GPU runs use nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get("STCAT_DIST_BACKEND", "nccl")
+    local = min(local, torch.cuda.device_count() - 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     _lib.load()
     _lib.set_mma_mode(args.mma)
@@ -228,9 +235,14 @@ def main():
     elapsed = dt.item()
 
     roof, kernels = None, None
-    if rank == 0 and not args.no_profile:
-        with LaunchProfiler() as prof:
+    if not args.no_profile:
+        # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events
+        if rank == 0:
+            with LaunchProfiler() as prof:
+                step()
+        else:
             step()
+    if rank == 0 and not args.no_profile:
         agg = prof.summary()
         kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                        "tflops": (round(v["flop"] / v["ms"] / 1e9, 2) if v["flop"] and v["ms"] else None)}
