@@ -258,3 +258,26 @@ def build_model(cfg=None, text_encoder=None):
 
 def build_postprocessors():
     return PostProcess()
+
+
+@torch.no_grad()
+def evaluate_video(model, postprocessor, videos: NestedTensor, texts, target_sizes, frame_ids: List[List[int]]):
+    """Counterpart of do_eval's per-batch body (engine/evaluate.py:97-119 with single_forward :38-77): the clip is
+    split into its even and odd frames, each half goes through the model and PostProcess, boxes are merged per
+    frame id and the temporal prediction is the union of the two spans."""
+    durations = videos.durations
+    boxes_by_frame, spans = {}, []
+    for start in (0, 1):
+        sub = videos.subsample(2, start)
+        ids = [fid[start::2] for fid in frame_ids]
+        sizes = torch.cat([ts[start::2] for ts in torch.split(target_sizes, durations)], dim=0)
+        out = model(sub, texts)
+        boxes, sted = postprocessor(out, sizes, ids, sub.durations)
+        at = 0
+        for v, fid in enumerate(ids):
+            for k, f in enumerate(fid):
+                boxes_by_frame[(v, f)] = boxes[at + k]
+            at += len(fid)
+        spans.append(sted)
+    union = [[min(a[0], b[0]), max(a[1], b[1])] for a, b in zip(*spans)]
+    return boxes_by_frame, union

@@ -210,3 +210,55 @@ def test_gpu_full_resolution_clip_forward():
     dev = use_hip()
     _compare(_run_hip(dev, 16, 448, 10, with_backward=False), _run_oracle(16, 448, 10, with_backward=False),
              with_backward=False)
+
+
+@pytest.mark.gpu
+def test_gpu_c2_forward():
+    """BASELINE config 2: HC-STVG-like T=32, 416x416 (13x13 map, S=180), forward only, bench mode (bf16x3)."""
+    dev = use_hip()
+    T, res, L = synth.CONFIGS["C2"]
+    _compare(_run_hip(dev, T, res, L, with_backward=False, mma="bf16x3"), _run_oracle(T, res, L, with_backward=False),
+             with_backward=False)
+
+
+@pytest.mark.gpu
+def test_gpu_c5_shaped_clip_forward():
+    """Long-query stress shape: 40 text tokens at 448x448 -> S = 237 tokens per frame (8 key tiles); T=12 keeps the
+    CPU oracle in seconds (the per-frame arithmetic is identical at T=128)."""
+    dev = use_hip()
+    _compare(_run_hip(dev, 12, 448, 40, with_backward=False, mma="bf16x3"),
+             _run_oracle(12, 448, 40, with_backward=False), with_backward=False)
+
+
+@pytest.mark.gpu
+def test_gpu_two_pass_eval_path():
+    """engine/evaluate.py:97-119: even/odd frame halves evaluated separately, spans united."""
+    from stcat_amd.pipeline import evaluate_video
+    from stcat_amd import _lib
+    dev = use_hip()
+    T, res, L = 8, 224, 10
+    _lib.set_mma_mode("bf16x3")
+    try:
+        model, _, _ = build_model(None, SyntheticText(synth.synth_text(L)))
+        model.eval()
+        synth.fill_module_(model)
+        model.to(dev)
+        frames = synth.synth_frames(T, res).to(dev)
+        mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+        sizes = torch.tensor([[float(res), float(res)]], device=dev).repeat(T, 1)
+        ids = [list(range(100, 100 + T))]
+        boxes, union = evaluate_video(model, build_postprocessors(), NestedTensor(frames, mask, [T]), ["q"], sizes, ids)
+    finally:
+        _lib.set_mma_mode("f32")
+    assert sorted(f for _, f in boxes) == ids[0] and all(b.shape == (4,) for b in boxes.values())
+    sd = synth.synth_state_dict()
+    spans = []
+    for start in (0, 1):
+        out = O.stcat_forward(sd, synth.synth_frames(T, res)[start::2], torch.zeros(T // 2, res, res, dtype=torch.bool),
+                              synth.synth_text(L))
+        b, sted, _ = O.post_process(out["pred_sted"], out["pred_boxes"], torch.ones(T // 2, 2) * res, ids[0][start::2],
+                                    T // 2)
+        spans.append(sted)
+        for k, f in enumerate(ids[0][start::2]):
+            close(boxes[(0, f)], b[k], OUT_TOL * res, f"eval box frame {f}")
+    assert union == [[min(spans[0][0], spans[1][0]), max(spans[0][1], spans[1][1])]]
