@@ -25,6 +25,17 @@ template <int NS>
 static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int plane_elems, float x0, float x1, float x2,
                                                            float x3) {
   float r[4] = {x0, x1, x2, x3};
+#ifdef STCAT_EXPERIMENT_NOSPLIT
+  {  // timing experiment only: truncate, same value in every plane (WRONG results, ~6x fewer VALU ops)
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    u16x4 pk;
+    STCAT_UNROLL
+    for (int e = 0; e < 4; ++e) pk[e] = (unsigned short)(__float_as_uint(r[e]) >> 16);
+    STCAT_UNROLL
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x4*>(dst + s * plane_elems) = pk;
+    return;
+  }
+#endif
   STCAT_UNROLL
   for (int s = 0; s < NS; ++s) {
     bf16x4 pk;
@@ -78,11 +89,13 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
     }                                                         \
   }
 
-// ---- R-type staging of a [ROWS x 32] tile: thread -> k4 = t&7, rows (t>>3) + 32*j -------------------
+// ---- R-type staging of a [ROWS x 32] tile: thread -> k4 = t&7, rows trow + 32*j.  trow permutes t>>3 inside
+// each group of 8 so that the two rows written by one 16-lane ds_write group are 4 rows (320 B) apart:
+// with 80-byte rows that puts them on disjoint halves of the 32 write banks (adjacent rows overlap by 4).
 #define STCAT_BS_STORE_R(DST, ROWS, REGS)                                                                \
   STCAT_UNROLL                                                                                           \
   for (int j = 0; j < (ROWS) / 32; ++j)                                                                  \
-    stcat_bs_split_store<NS>(&(DST)[((t >> 3) + 32 * j) * LDK + (t & 7) * 4], (ROWS) * LDK, (REGS)[j].x, \
+    stcat_bs_split_store<NS>(&(DST)[(trow + 32 * j) * LDK + (t & 7) * 4]    , (ROWS) * LDK, (REGS)[j].x, \
                              (REGS)[j].y, (REGS)[j].z, (REGS)[j].w);
 
 // ---- O-type staging of a [32(k) x ROWS] tile: block i = t + 256*j -> kgrp = i & 7 (4 k's), rowgrp = i >> 3 (4 rows).
@@ -111,7 +124,7 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
   int cur_tap = -1;                                                                                      \
   STCAT_UNROLL                                                                                           \
   for (int j = 0; j < (ROWS) / 32; ++j) {                                                                \
-    const int m = m0 + (t >> 3) + 32 * j;                                                                \
+    const int m = m0 + trow + 32 * j;                                                                    \
     a_off[j] = STCAT_BUF_OOB;                                                                            \
     if (m < p.M) {                                                                                       \
       const int ohw = g.OH * g.OW;                                                                       \
@@ -134,26 +147,61 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
         a_off[j] = pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (t & 7) * 16;                         \
       }                                                                                                  \
     }                                                                                                    \
+    const stcat_buf_t bA_ = stcat_make_buf(p.A, (KT) < nk ? p.a_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
-    for (int j = 0; j < (ROWS) / 32; ++j) ra[SET][j] = stcat_buf_ld4(bufA, a_off[j], (unsigned)c0 * 4);  \
+    for (int j = 0; j < (ROWS) / 32; ++j) ra[SET][j] = stcat_buf_ld4(bA_, a_off[j], (unsigned)c0 * 4);   \
   }
 
 // Software pipeline shared by the three kernels: LDS double buffer + two register sets, so the global loads of
-// K-tile kt+2 are in flight during the MFMA phases of tiles kt and kt+1.
+// K-tile kt+2 are in flight during the MFMA phases of tiles kt and kt+1.  The prefetch is issued
+// UNCONDITIONALLY (a K-tile past the end is loaded through a zero-length buffer descriptor: hardware zero
+// fill, no memory traffic): a branch around the loads makes the compiler's s_waitcnt conservative
+// (vmcnt counted as if the loads were skipped), which drains the new loads every iteration.
+#if defined(STCAT_EXP_NOLOAD)
+#define STCAT_EXP_LOAD(L) if (kt < 0) { L }
+#else
+#define STCAT_EXP_LOAD(L) L
+#endif
+#if defined(STCAT_EXP_NOSTORE)
+#define STCAT_EXP_STORE(S) if (kt < 0) { S }
+#else
+#define STCAT_EXP_STORE(S) S
+#endif
+#if defined(STCAT_EXP_NOMFMA)
+#define STCAT_EXP_COMPUTE(C) if (kt < 0) { C }
+#else
+#define STCAT_EXP_COMPUTE(C) C
+#endif
+// Scheduling request for the block [prefetch loads | fragment reads | MFMAs]: spread the global loads between
+// MFMA groups.  A wave issues in order and a buffer load only issues when the CU's address/L1 path accepts it
+// (~33 B/clk/CU measured); with all loads clustered at the top of the iteration every wave of the CU queues
+// there before its first MFMA, and load time ADDS to matrix time instead of hiding under it.
+#ifdef STCAT_EXP_NOINTERLEAVE
+#define STCAT_BS_INTERLEAVE_VMEM
+#else
+#define STCAT_BS_INTERLEAVE_VMEM                                                                         \
+  STCAT_UNROLL                                                                                           \
+  for (int i_ = 0; i_ < 8; ++i_) {                                                                       \
+    STCAT_SCHED_GROUP(0x008, 2);                                                                         \
+    STCAT_SCHED_GROUP(0x020, 1);                                                                         \
+  }
+#endif
 #define STCAT_BS_PIPELINE(LOAD, STORE)                                                                   \
   LOAD(0, 0)                                                                                             \
-  if (nk > 1) { LOAD(1, 1) }                                                                             \
+  LOAD(1, 1)                                                                                             \
   STORE(0, 0)                                                                                            \
   __syncthreads();                                                                                       \
   for (int kt = 0; kt < nk; kt += 2) {                                                                   \
-    if (kt + 2 < nk) { LOAD(kt + 2, 0) }                                                                 \
-    STCAT_BS_COMPUTE(As[0], Bs[0])                                                                       \
-    if (kt + 1 < nk) { STORE(1, 1) }                                                                     \
+    STCAT_EXP_LOAD(LOAD(kt + 2, 0))                                                                      \
+    STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[0], Bs[0]))                                                    \
+    STCAT_BS_INTERLEAVE_VMEM                                                                             \
+    if (kt + 1 < nk) { STCAT_EXP_STORE(STORE(1, 1)) }                                                    \
     __syncthreads();                                                                                     \
     if (kt + 1 >= nk) break;                                                                             \
-    if (kt + 3 < nk) { LOAD(kt + 3, 1) }                                                                 \
-    STCAT_BS_COMPUTE(As[1], Bs[1])                                                                       \
-    if (kt + 2 < nk) { STORE(0, 0) }                                                                     \
+    STCAT_EXP_LOAD(LOAD(kt + 3, 1))                                                                      \
+    STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[1], Bs[1]))                                                    \
+    STCAT_BS_INTERLEAVE_VMEM                                                                             \
+    if (kt + 2 < nk) { STCAT_EXP_STORE(STORE(0, 0)) }                                                    \
     __syncthreads();                                                                                     \
   }
 
@@ -182,6 +230,7 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
   float* Cs = reinterpret_cast<float*>(smem_raw); /* epilogue: the fp32 output tile, rows padded to LDC */ \
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;                                               \
   const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;                              \
+  const int trow = ((t >> 3) & ~7) | (((t >> 3) & 1) << 2) | ((t >> 4) & 3);                             \
   const int num_n = p.N / BN;                                                                            \
   const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);                                                  \
   const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;                                                \
@@ -199,7 +248,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   STCAT_BS_ACC_INIT
   unsigned b_off[BN / 32];
   STCAT_UNROLL
-  for (int j = 0; j < BN / 32; ++j) b_off[j] = (unsigned)((n0 + (t >> 3) + 32 * j) * p.ldb + (t & 7) * 4) * 4;
+  for (int j = 0; j < BN / 32; ++j) b_off[j] = (unsigned)((n0 + trow + 32 * j) * p.ldb + (t & 7) * 4) * 4;
   float4 ra[2][BM / 32], rb[2][BN / 32];
   const int nk = p.K / BK;
 #define STCAT_BSF_LOAD(KT, SET)                                                                          \
@@ -207,8 +256,9 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   {                                                                                                      \
     const int r0b = (KT) * BK, tapb = r0b / g.C, c0b = r0b - tapb * g.C;                                 \
     const unsigned soffb = (unsigned)tapb * p.b_tap_stride + (unsigned)c0b * 4;                          \
+    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < nk ? p.b_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
-    for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bufB, b_off[j], soffb);                 \
+    for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bB_, b_off[j], soffb);                  \
   }
 #define STCAT_BSF_STORE(SET, BUF) \
   STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
@@ -276,10 +326,11 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
   {                                                                                                      \
     const int r0 = (KT) * BK, tap = r0 / g.C, co0 = r0 - tap * g.C;                                      \
     const unsigned soff = (unsigned)(co0 * p.ldb + tap * p.N) * 4;                                       \
+    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < nk ? p.b_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < JB; ++j) {                                                                       \
       STCAT_UNROLL                                                                                       \
-      for (int e = 0; e < 4; ++e) rb[SET][j][e] = stcat_buf_ld4(bufB, b_off[j][e], soff);                \
+      for (int e = 0; e < 4; ++e) rb[SET][j][e] = stcat_buf_ld4(bB_, b_off[j][e], soff);                 \
     }                                                                                                    \
   }
 #define STCAT_BSD_STORE(SET, BUF) \

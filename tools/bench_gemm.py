@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    L.load()
+    L.load(os.environ.get("STCAT_LIB_OVERRIDE", L.LIB_PATH))  # experiment builds only
     L.set_mma_mode(args.mma)
     if args.tile:
         bm, bn = [int(v) for v in args.tile.split("x")]

@@ -1,12 +1,11 @@
 #!/bin/bash
-# GPU-box probe: GEMM microbench in several modes/tiles + PMC counters for one bf16x3 conv shape.
-mkdir -p gpurun_out
-timeout 120 python tools/bench_gemm.py --mma f32 2>&1 | tail -15
-timeout 120 python tools/bench_gemm.py --mma bf16x3 2>&1 | tail -15
-timeout 120 python tools/bench_gemm.py --mma bf16x3 --tile 128x64 2>&1 | tail -15
-timeout 120 python tools/bench_gemm.py --mma bf16x3 --tile 64x64 2>&1 | tail -15
-R=$PWD; cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d /tmp/pmc1 -o p -- python $R/tools/bench_gemm.py --mma bf16x3 --only "l3.conv2" > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc2 -o p -- python $R/tools/bench_gemm.py --mma bf16x3 --only "l3.conv2" > /dev/null 2>&1
-cd $R
-python tools/pmc_summary.py /tmp/pmc1 /tmp/pmc2
+# GEMM-family microbench (bf16x3): experiment libraries (timing only, wrong results) vs the product library
+for lib in stcat_amd/lib/libstcat_exp*.so; do
+  [ -f "$lib" ] || continue
+  echo "== $lib"
+  STCAT_LIB_OVERRIDE=$PWD/$lib timeout 200 python tools/bench_gemm.py --mma bf16x3 2>&1 | tail -13 | grep -E "TOTAL|l3.conv2|l2.conv2|l3.conv1|l1.conv2" | cut -c1-150
+done
+if [ "$1" != "exp-only" ]; then
+echo "== product build"
+timeout 200 python tools/bench_gemm.py --mma bf16x3 2>&1 | tail -13 | cut -c1-150
+fi
