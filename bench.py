@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--mma", default="bf16x3", choices=["f32", "bf16x3", "bf16x6"],
                     help="arithmetic of the conv/Linear GEMM family (fp32 tensors in HBM in every mode); bf16x3 is the "
                          "split-product parity mode of SURVEY.md §7 hard part 3 (meets the 1e-3 / bit-exact-span bars)")
+    ap.add_argument("--eval-mode", action="store_true",
+                    help="run the step with dropout off (the parity configuration); default is train mode, "
+                         "dropout 0.1 / 0.3 active as in the reference's training loop")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
@@ -191,7 +194,11 @@ def main():
 
     T, res, L = synth.CONFIGS[args.config]
     model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
-    model.eval()  # dropout off (parity mode); gradients flow
+    if args.eval_mode:
+        model.eval()  # dropout off (parity mode); gradients flow
+    else:
+        model.train()  # the measured workload: dropout active (FrozenBN has no train-mode state)
+        ops.manual_seed(20260929, rank)
     synth.fill_module_(model)
     model.to(dev)
     reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0)
@@ -294,6 +301,7 @@ def main():
                       "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
+                       "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",
                        "allreduce_bytes": reducer.message_bytes},
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "kernels": kernels,
         }

@@ -39,11 +39,12 @@ SIGNATURES: Dict[str, str] = {
     "stcat_layernorm_fwd": "pppppppiifs",
     "stcat_layernorm_bwd": "pppppppppiis",
     "stcat_ew": "ipppp" + "llffs",
-    "stcat_mha_self_fwd": "ppppppiiiiiiifs",
-    "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiifs",
-    "stcat_attn_weights_mean": "ppiiis",
-    "stcat_attn_q1_fwd": "pppppppp" + "iiiiiifs",
-    "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiifs",
+    "stcat_dropout": "ppplflls",
+    "stcat_mha_self_fwd": "ppppppiiiiiiif" + "flls",
+    "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "flls",
+    "stcat_attn_weights_mean": "ppiii" + "flls",
+    "stcat_attn_q1_fwd": "pppppppp" + "iiiiiif" + "flls",
+    "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "flls",
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_debug_force_tile": "ii",
     "stcat_set_mma_mode": "i",

@@ -19,6 +19,7 @@
 //     This is GEMV-class and HBM-bound; one wave per (frame, head), lanes over keys.
 #pragma once
 #include "stcat_platform.h"
+#include "stcat_rng.h"
 
 struct AttnParams {
   const float* Q;  // [B][S][ldq], head h at column h*32
@@ -30,6 +31,8 @@ struct AttnParams {
   int B, H, S;
   int ldq, ldk, ldv, ldo;
   float scale;
+  DropParams drop;   // dropout on the probabilities (attention.py:381 / nn.MultiheadAttention); Pt keeps the
+                     // UNdropped softmax, every consumer regenerates the mask from counter (bh*Sp + key)*Sp + query
 };
 
 
@@ -111,7 +114,8 @@ __global__ void __launch_bounds__(64 * NT) mha_self_fwd_kernel(AttnParams p) {
       const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const float pr = sc[kt][r] * inv;
       Ptg[(long)key * SP + q] = pr;
-      o = STCAT_MFMA_32x32x2(pr, Vs[key * 32 + l31], o);
+      const float pd = pr * stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      o = STCAT_MFMA_32x32x2(pd, Vs[key * 32 + l31], o);
     }
   }
   float* Og = p.O + (long)b * p.S * p.ldo + h * 32 + l31;
@@ -138,6 +142,7 @@ struct AttnBwdParams {
   int B, H, S;
   int ldq, ldk, ldv, ldo, ldg, ldgv;  // ldg: row stride of dQ and dK, ldgv: of dV
   float scale;
+  DropParams drop;
 };
 
 // backward, phase 1: one wave per query tile -> dS (stored key-major, pre-multiplied by scale) and dQ
@@ -201,6 +206,7 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_kernel(AttnBwdParams 
       const int key = krel + 4 * hi;
       float dpv = dp[r];
       if (p.dW && q < p.S && key < p.S) dpv += p.dW[((long)b * p.S + q) * p.S + key] * invH;
+      dpv *= stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);  // dP = M' * dP'
       const float ds = Ptg[(long)krel * SP] * (dpv - delta) * p.scale;
       dStg[(long)krel * SP] = ds;
       dq = STCAT_MFMA_32x32x2(ds, Ks[key * 32 + l31], dq);
@@ -243,9 +249,14 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams
   for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
   // reduction over queries in chunks of 8: half `hi` feeds queries qc*8 + hi*4 + e
   for (int qc = 0; qc < SP / 8; ++qc) {
-    const float4 pv = stcat_ld4(Prow + qc * 8);
+    float4 pv = stcat_ld4(Prow + qc * 8);
     const float4 sv = stcat_ld4(Srow + qc * 8);
     const int qb = qc * 8 + hi * 4;
+    if (p.drop.thresh) {  // dV = P'^T dO with P' = M' * P
+      const unsigned long long c0 = ((unsigned long long)blockIdx.x * SP + key) * SP + qb;
+      pv.x *= stcat_drop_mul(p.drop, c0); pv.y *= stcat_drop_mul(p.drop, c0 + 1);
+      pv.z *= stcat_drop_mul(p.drop, c0 + 2); pv.w *= stcat_drop_mul(p.drop, c0 + 3);
+    }
     dv = STCAT_MFMA_32x32x2(pv.x, dOs[(qb + 0) * 32 + l31], dv);
     dk = STCAT_MFMA_32x32x2(sv.x, Qs[(qb + 0) * 32 + l31], dk);
     dv = STCAT_MFMA_32x32x2(pv.y, dOs[(qb + 1) * 32 + l31], dv);
@@ -269,25 +280,31 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams
 
 // head-averaged attention weights W[b][q][k] = mean_h P[b][h][q][k]  (nn.MultiheadAttention
 // need_weights=True; consumed only for the time decoder: pipeline.py:84-85)
-__global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H, int S, int SP) {
+__global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H, int S, int SP, DropParams drop) {
   const long n = (long)B * S * S;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % S), q = (int)((i / S) % S), b = (int)(i / ((long)S * S));
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc += Pt[(((long)b * H + h) * SP + k) * SP + q];
+    for (int h = 0; h < H; ++h) {
+      const long c = (((long)b * H + h) * SP + k) * SP + q;
+      acc += Pt[c] * stcat_drop_mul(drop, (unsigned long long)c);  // train mode returns the DROPPED weights
+    }
     W[i] = acc / (float)H;
   }
 }
 
 // corr[b][h][q] = (1/H) sum_k P[b][h][q][k] * dW[b][q][k]   (softmax-backward delta term of the
 // head-averaged weights gradient; only the time decoder's self-attention has one)
-__global__ void attn_dw_corr_kernel(const float* Pt, const float* dW, float* corr, int B, int H, int S, int SP) {
+__global__ void attn_dw_corr_kernel(const float* Pt, const float* dW, float* corr, int B, int H, int S, int SP,
+                                    DropParams drop) {
   const long n = (long)B * H * S;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % S), h = (int)((i / S) % H), b = (int)(i / ((long)S * H));
     float acc = 0.f;
-    for (int k = 0; k < S; ++k)
-      acc += Pt[(((long)b * H + h) * SP + k) * SP + q] * dW[((long)b * S + q) * S + k];
+    for (int k = 0; k < S; ++k) {
+      const long c = (((long)b * H + h) * SP + k) * SP + q;
+      acc += Pt[c] * stcat_drop_mul(drop, (unsigned long long)c) * dW[((long)b * S + q) * S + k];
+    }
     corr[i] = acc / (float)H;
   }
 }
@@ -314,6 +331,7 @@ struct AttnQ1Params {
   int B, H, S;
   int ldq, ldk, ldv;
   float scale;
+  DropParams drop;  // counter = bh * S + s; P keeps the undropped softmax
 };
 
 #define STCAT_Q1_MAXC 4  // S <= 256
@@ -373,7 +391,7 @@ __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
   for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
     const int s = c * 64 + lane;
     const float pr = sc[c] * inv;
-    ps[w][s] = pr;
+    ps[w][s] = pr * stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
     if (live && s < p.S) p.P[(long)bh * p.S + s] = pr;
   }
   __syncthreads();
@@ -402,13 +420,14 @@ __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
     float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
   }
-  float pr[STCAT_Q1_MAXC], dp[STCAT_Q1_MAXC];
+  float pr[STCAT_Q1_MAXC], dp[STCAT_Q1_MAXC], dm[STCAT_Q1_MAXC];
   float delta = 0.f;
   STCAT_UNROLL
   for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
     const int s = c * 64 + lane;
     pr[c] = 0.f;
     dp[c] = 0.f;
+    dm[c] = 1.f;
     if (s < p.S) {
       pr[c] = p.P[(long)bh * p.S + s];
       const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
@@ -418,8 +437,9 @@ __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
         float4 vv = stcat_ld4(vr + d4 * 4);
         dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
       }
-      dp[c] = dot;
-      delta += pr[c] * dot;
+      dm[c] = stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
+      dp[c] = dot * dm[c];  // dP = M' * (dO . V)
+      delta += pr[c] * dp[c];
     }
   }
   delta = stcat_wave_sum(delta);
@@ -427,14 +447,15 @@ __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
   for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
     const int s = c * 64 + lane;
     const float ds = pr[c] * (dp[c] - delta) * p.scale;
+    const float pd = pr[c] * dm[c];  // dV = P' dO
     dss[w][s] = ds;
     if (live && s < p.S) {
       float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
       float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
       STCAT_UNROLL
       for (int d4 = 0; d4 < 8; ++d4) {
-        stcat_st4(gv + d4 * 4, make_float4(pr[c] * go[d4 * 4], pr[c] * go[d4 * 4 + 1], pr[c] * go[d4 * 4 + 2],
-                                           pr[c] * go[d4 * 4 + 3]));
+        stcat_st4(gv + d4 * 4, make_float4(pd * go[d4 * 4], pd * go[d4 * 4 + 1], pd * go[d4 * 4 + 2],
+                                           pd * go[d4 * 4 + 3]));
         stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2],
                                             ds * qa[d4 * 4 + 3]));
       }

@@ -4,6 +4,7 @@
 // All are wave64 kernels with 16-byte accesses where the layout allows it.
 #pragma once
 #include "stcat_platform.h"
+#include "stcat_rng.h"
 
 // ---------------------------------------------------------------------------------
 // LayerNorm over D = 256 (torch.nn.LayerNorm(256), eps 1e-5: modal_encoder.py:218-219,
@@ -364,5 +365,25 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* w, f
   for (int r = ty; r < 32; r += 8) {
     const int ci = ci0 + r, co = co0 + tx;
     if (ci < Cin && co < Cout) wt[((long)tap * Cin + ci) * Cout + co] = tile[tx][r];
+  }
+}
+
+// y = res + dropout(x)   (res may be null; the same launch on dY is the backward of the x branch)
+__global__ void dropout_kernel(const float* x, const float* res, float* y, long n, DropParams d) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      float4 v = stcat_ld4(x + i);
+      v.x *= stcat_drop_mul(d, (unsigned long long)i);
+      v.y *= stcat_drop_mul(d, (unsigned long long)i + 1);
+      v.z *= stcat_drop_mul(d, (unsigned long long)i + 2);
+      v.w *= stcat_drop_mul(d, (unsigned long long)i + 3);
+      if (res) {
+        const float4 r = stcat_ld4(res + i);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      stcat_st4(y + i, v);
+    } else {
+      for (long j = i; j < n; ++j) y[j] = x[j] * stcat_drop_mul(d, (unsigned long long)j) + (res ? res[j] : 0.f);
+    }
   }
 }

@@ -43,7 +43,8 @@ class SeqEmbeddingSine(nn.Module):
 
 
 class MLP(nn.Module):
-    """models/net_utils.py:7-26 (inference-mode arithmetic: dropout is identity)."""
+    """models/net_utils.py:7-26.  In train mode the reference applies dropout after EVERY layer, the output layer
+    included (`i < self.num_layers` is always true, net_utils.py:24) — mirrored here."""
 
     def __init__(self, input_dim, hidden_dim, output_dim, num_layers, dropout=0):
         super().__init__()
@@ -53,13 +54,27 @@ class MLP(nn.Module):
         self.dropout_p = dropout
 
     def forward(self, x):
+        p = self.dropout_p if self.training else 0.0
         for i, layer in enumerate(self.layers):
-            x = ops.linear(x, layer.weight, layer.bias, relu=(i < self.num_layers - 1))
+            x = ops.dropout(ops.linear(x, layer.weight, layer.bias, relu=(i < self.num_layers - 1)), p)
         return x
 
 
 def _lin(m: nn.Linear, x, res=None, relu=False):
     return ops.linear(x, m.weight, m.bias, res=res, relu=relu)
+
+
+def _lin_res(w, b, x, res, p: float):
+    """res + dropout_p(x W^T + b): the residual rides in the GEMM epilogue when dropout is off (eval)."""
+    if p > 0.0:
+        return ops.dropout_add(ops.linear(x, w, b), res, p)
+    return ops.linear(x, w, b, res=res)
+
+
+def _ffn(layer, x, p: float):
+    """x + dropout(linear2(dropout(relu(linear1 x))))  (modal_encoder.py:239-240; query_decoder.py:435-436, 657-658)"""
+    h = ops.dropout(_lin(layer.linear1, x, relu=True), p)
+    return _lin_res(layer.linear2.weight, layer.linear2.bias, h, x, p)
 
 
 def _ln(m: nn.LayerNorm, x):
@@ -87,19 +102,20 @@ class TransformerEncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.nhead = nhead
+        self.dropout_p = dropout
 
     def run(self, x, pos, kpm, pos_is_const: bool):
         """x, pos: [B,S,256] batch-first; kpm [B,S] bool or None."""
         D = x.shape[-1]
+        p = self.dropout_p if self.training else 0.0
         W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         qk_in = ops.add_const(x, pos) if pos_is_const else ops.add(x, pos)      # q = k = src + pos   :234
         qk = ops.linear(qk_in, W[:2 * D], Bi[:2 * D])                           # packed q|k projection
         v = ops.linear(x, W[2 * D:], Bi[2 * D:])                                # value = src         :236
-        a, _ = ops.mha_self_packed(qk, v, kpm, (D // self.nhead) ** -0.5)
-        z = ops.linear(a, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=x)
+        a, _ = ops.mha_self_packed(qk, v, kpm, (D // self.nhead) ** -0.5, drop_p=p)
+        z = _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a, x, p)
         x = _ln(self.norm1, z)                                                  # :237-238
-        h = _lin(self.linear1, x, relu=True)
-        return _ln(self.norm2, _lin(self.linear2, h, res=x))                    # :239-241
+        return _ln(self.norm2, _ffn(self, x, p))                                # :239-241
 
 
 class SpatialTemporalEncoder(nn.Module):
@@ -232,12 +248,14 @@ class TransformerDecoderLayer(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
         self.norm4 = nn.LayerNorm(d_model)
         self.nhead = nhead
+        self.dropout_p = dropout
 
     def run(self, tgt, kc, kpos, vv, kpm, query_pos, time_embed, query_sine, first: bool):
         """tgt/query_pos/time_embed/query_sine [T,256]; kc/kpos/vv [n,S',256] = this layer's ca_kcontent_proj(memory),
         ca_kpos_proj(pos), ca_v_proj(memory) — column blocks of the layer-batched projections (QueryDecoder.run)."""
         T, D = tgt.shape
         hd = D // self.nhead
+        p = self.dropout_p if self.training else 0.0
         W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         q = ops.add3(_lin(self.sa_qcontent_proj, tgt), _lin(self.sa_qtime_proj, time_embed),
                      _lin(self.sa_qpos_proj, query_pos))                                     # :329-338
@@ -247,8 +265,8 @@ class TransformerDecoderLayer(nn.Module):
         qp = ops.linear(q, W[:D], Bi[:D])                                                    # nn.MHA in-proj :341
         kp_ = ops.linear(k, W[D:2 * D], Bi[D:2 * D])
         vp = ops.linear(v, W[2 * D:], Bi[2 * D:])
-        a, _ = ops.mha_self(qp[None], kp_[None], vp[None], None, hd ** -0.5)
-        tgt = _ln(self.norm1, ops.linear(a[0], self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt))
+        a, _ = ops.mha_self(qp[None], kp_[None], vp[None], None, hd ** -0.5, drop_p=p)
+        tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
 
         qc = _lin(self.ca_qcontent_proj, tgt)
         if first:                                                                            # :360-366
@@ -256,10 +274,9 @@ class TransformerDecoderLayer(nn.Module):
             kpos = kpos.contiguous()  # k1 and k2 must share one leading dimension in the kernel
             kc = ops.add(kc.contiguous(), kpos)
         qs = _lin(self.ca_qpos_sine_proj, query_sine)                                        # :369
-        a = ops.attn_q1(qc, qs, kc, kpos, vv, kpm, (2 * hd) ** -0.5)                         # :368-409
-        tgt = _ln(self.norm3, _lin(self.cross_attn.out_proj, a, res=tgt))                    # :431-432
-        h = _lin(self.linear1, tgt, relu=True)
-        return _ln(self.norm4, _lin(self.linear2, h, res=tgt))
+        a = ops.attn_q1(qc, qs, kc, kpos, vv, kpm, (2 * hd) ** -0.5, drop_p=p)               # :368-409
+        tgt = _ln(self.norm3, _lin_res(self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias, a, tgt, p))  # :431
+        return _ln(self.norm4, _ffn(self, tgt, p))                                           # :435-437
 
 
 class TransformerDecoder(nn.Module):
@@ -322,24 +339,25 @@ class TimeDecoderLayer(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
         self.norm4 = nn.LayerNorm(d_model)
         self.nhead = nhead
+        self.dropout_p = dropout
 
     def run(self, tgt, kc, vv, kpm, query_pos, qpos_time):
         """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory."""
         T, D = tgt.shape
         hd = D // self.nhead
+        p = self.dropout_p if self.training else 0.0
         W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         qk_in = ops.add(tgt, qpos_time)                                                      # :602
         qk = ops.linear(qk_in, W[:2 * D], Bi[:2 * D])
         v = ops.linear(tgt, W[2 * D:], Bi[2 * D:])
-        a, w = ops.mha_self_packed(qk[None], v[None], None, hd ** -0.5, need_weights=True)   # :604-610
-        tgt = _ln(self.norm1, ops.linear(a[0], self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt))
+        a, w = ops.mha_self_packed(qk[None], v[None], None, hd ** -0.5, need_weights=True, drop_p=p)   # :604-610
+        tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
         Wc, Bc = self.cross_attn_image.in_proj_weight, self.cross_attn_image.in_proj_bias
         qc = ops.linear(ops.add(tgt, query_pos), Wc[:D], Bc[:D])                             # :633-634
-        a = ops.attn_q1(qc, None, kc, None, vv, kpm, hd ** -0.5)
-        tgt = _ln(self.norm3, ops.linear(a, self.cross_attn_image.out_proj.weight,
-                                         self.cross_attn_image.out_proj.bias, res=tgt))
-        h = _lin(self.linear1, tgt, relu=True)
-        return _ln(self.norm4, _lin(self.linear2, h, res=tgt)), w
+        a = ops.attn_q1(qc, None, kc, None, vv, kpm, hd ** -0.5, drop_p=p)
+        tgt = _ln(self.norm3, _lin_res(self.cross_attn_image.out_proj.weight, self.cross_attn_image.out_proj.bias,
+                                       a, tgt, p))                                            # :653-654
+        return _ln(self.norm4, _ffn(self, tgt, p)), w                                        # :657-659
 
 
 class TimeDecoder(nn.Module):

@@ -398,6 +398,92 @@ def pos_sine_2d(mask: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------
+# dropout (train mode)
+# ------------------------------------------------------------------------------------
+_MASK64 = (1 << 64) - 1
+
+
+class _DropoutStream:
+    """(seed, running element counter) of this process.  Every dropout site of a step takes a fresh counter range
+    (csrc/stcat_rng.h); the backward pass replays the range saved by its forward.  DP ranks must seed differently
+    (manual_seed(seed, rank)), exactly as torch's per-process generators differ."""
+
+    def __init__(self):
+        self.seed = 0x5DEECE66D
+        self.offset = 0
+
+    def take(self, numel: int):
+        off = self.offset
+        self.offset = (off + ((numel + 3) // 4) * 4) & ((1 << 62) - 1)
+        return self.seed, off
+
+
+_dropout_stream = _DropoutStream()
+
+
+def manual_seed(seed: int, rank: int = 0) -> None:
+    """Seed the dropout stream of this process (counter restarts at 0)."""
+    z = (seed * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & _MASK64
+    z ^= z >> 31
+    _dropout_stream.seed = z & ((1 << 62) - 1)
+    _dropout_stream.offset = 0
+
+
+def dropout_stream_state():
+    return _dropout_stream.seed, _dropout_stream.offset
+
+
+def dropout_keep_mask(seed: int, offset: int, n: int, p: float):
+    """Host twin of csrc/stcat_rng.h (numpy uint64): bool[n], True = kept.  Test/debug helper; the product path
+    never materialises a mask."""
+    import numpy as np
+    if p <= 0.0:
+        return np.ones(n, dtype=bool)
+    thresh = min(int(float(np.float32(p)) * 4294967296.0), 4294967295) or 1
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n, dtype=np.uint64) + np.uint64(offset) + np.uint64(1)
+        z = np.uint64(seed) + ctr * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(32)) >= np.uint64(thresh)
+
+
+class DropoutFn(Function):
+    """y = res + dropout_p(x) (res optional): nn.Dropout of modal_encoder.py:237-240, query_decoder.py:344, 431-436,
+    612, 653-658, net_utils.py:24-25.  Backward = the same launch on dY (mask regenerated, never stored)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p):
+        x = _c(x)
+        r = _c(res) if res is not None else None
+        seed, off = _dropout_stream.take(x.numel())
+        y = torch.empty_like(x)
+        L.call("stcat_dropout", x.data_ptr(), L._ptr(r), y.data_ptr(), x.numel(), float(p), seed, off, L.stream_of(x))
+        ctx.drop = (float(p), seed, off)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        p, seed, off = ctx.drop
+        dx = torch.empty_like(g)
+        L.call("stcat_dropout", g.data_ptr(), None, dx.data_ptr(), g.numel(), p, seed, off, L.stream_of(g))
+        return dx, (g if ctx.has_res else None), None
+
+
+def dropout(x, p: float):
+    """dropout_p(x); callers pass p = 0 in eval mode (identity, no launch)."""
+    return DropoutFn.apply(x, None, p) if p > 0.0 else x
+
+
+def dropout_add(x, res, p: float):
+    """res + dropout_p(x)."""
+    return DropoutFn.apply(x, res, p) if p > 0.0 else add(x, res)
+
+
+# ------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------
 def _ld3(t: torch.Tensor) -> int:
@@ -413,7 +499,7 @@ class MhaSelfFn(Function):
     q, k, v: [B,S,256] views (e.g. column slices of a packed projection).  Returns (out, weights|None)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kpm, scale, need_weights, packed_qk):
+    def forward(ctx, q, k, v, kpm, scale, need_weights, packed_qk, drop_p=0.0):
         B, S, D = v.shape
         H = D // 32
         _chk(q, k, v)
@@ -423,12 +509,16 @@ class MhaSelfFn(Function):
         SP = ((S + 31) // 32) * 32
         o = _empty(v, B, S, D)
         pt = _empty(v, B, H, SP, SP)
+        drop = (0.0, 0, 0)
+        if drop_p > 0.0:  # dropout on the probabilities (nn.MultiheadAttention(dropout=p) in train mode)
+            drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP)
         L.call("stcat_mha_self_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), pt.data_ptr(),
-               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, L.stream_of(v))
+               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, *drop, L.stream_of(v))
         wts = None
         if need_weights:
             wts = _empty(v, B, S, S)
-            L.call("stcat_attn_weights_mean", pt.data_ptr(), wts.data_ptr(), B, H, S, L.stream_of(v))
+            L.call("stcat_attn_weights_mean", pt.data_ptr(), wts.data_ptr(), B, H, S, *drop, L.stream_of(v))
+        ctx.drop = drop
         ctx.save_for_backward(q, k, v, o, pt)
         ctx.scale = scale
         ctx.packed_qk = packed_qk
@@ -460,21 +550,21 @@ class MhaSelfFn(Function):
         dv = _empty(v, B, S, D)
         L.call("stcat_mha_self_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(),
                pt.data_ptr(), L._ptr(dw), L._ptr(corr), dst.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, ldg_qk, D, ctx.scale, L.stream_of(v))
+               B, H, S, _ld3(q), _ld3(k), _ld3(v), D, ldg_qk, D, ctx.scale, *ctx.drop, L.stream_of(v))
         if ctx.packed_qk:
-            return dqk, None, dv, None, None, None, None
-        return dq, dk, dv, None, None, None, None
+            return dqk, None, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
-def mha_self(q, k, v, kpm, scale, need_weights=False):
-    return MhaSelfFn.apply(q, k, v, kpm, scale, need_weights, False)
+def mha_self(q, k, v, kpm, scale, need_weights=False, drop_p=0.0):
+    return MhaSelfFn.apply(q, k, v, kpm, scale, need_weights, False, drop_p)
 
 
-def mha_self_packed(qk, v, kpm, scale, need_weights=False):
+def mha_self_packed(qk, v, kpm, scale, need_weights=False, drop_p=0.0):
     """q = qk[..., :D], k = qk[..., D:] come from one packed projection; the gradient is
     returned for the packed tensor directly."""
     D = v.shape[-1]
-    return MhaSelfFn.apply(qk, qk[:, :, D:], v, kpm, scale, need_weights, True)
+    return MhaSelfFn.apply(qk, qk[:, :, D:], v, kpm, scale, need_weights, True, drop_p)
 
 
 class AttnQ1Fn(Function):
@@ -483,7 +573,7 @@ class AttnQ1Fn(Function):
     q1/q2: [B,256] (q2 optional second 32-wide part per head); k1/k2: [B,S,256]; v: [B,S,256]."""
 
     @staticmethod
-    def forward(ctx, q1, q2, k1, k2, v, kpm, scale):
+    def forward(ctx, q1, q2, k1, k2, v, kpm, scale, drop_p=0.0):
         B, S, D = v.shape
         H = D // 32
         q1, q2 = _c(q1), _c(q2)
@@ -493,8 +583,12 @@ class AttnQ1Fn(Function):
         kp = _c(kpm.to(torch.uint8)) if kpm is not None else None
         out = _empty(v, B, D)
         P = _empty(v, B, H, S)
+        drop = (0.0, 0, 0)
+        if drop_p > 0.0:
+            drop = (float(drop_p),) + _dropout_stream.take(B * H * S)
+        ctx.drop = drop
         L.call("stcat_attn_q1_fwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), L._ptr(kp),
-               out.data_ptr(), P.data_ptr(), B, H, S, D, ldk, ldv, scale, L.stream_of(v))
+               out.data_ptr(), P.data_ptr(), B, H, S, D, ldk, ldv, scale, *drop, L.stream_of(v))
         ctx.save_for_backward(q1, q2, k1, k2, v, P)
         ctx.scale = scale
         return out
@@ -512,8 +606,8 @@ class AttnQ1Fn(Function):
         dv = _empty(v, B, S, D)
         L.call("stcat_attn_q1_bwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), P.data_ptr(),
                g.data_ptr(), dq1.data_ptr(), L._ptr(dq2), dk1.data_ptr(), L._ptr(dk2), dv.data_ptr(), B, H, S, D,
-               _ld3(k1), _ld3(v), ctx.scale, L.stream_of(v))
-        return dq1, dq2, dk1, dk2, dv, None, None
+               _ld3(k1), _ld3(v), ctx.scale, *ctx.drop, L.stream_of(v))
+        return dq1, dq2, dk1, dk2, dv, None, None, None
 
 
 class SplitColsFn(Function):
@@ -539,8 +633,8 @@ def split_cols(x, n):
     return SplitColsFn.apply(x, n)
 
 
-def attn_q1(q1, q2, k1, k2, v, kpm, scale):
-    return AttnQ1Fn.apply(q1, q2, k1, k2, v, kpm, scale)
+def attn_q1(q1, q2, k1, k2, v, kpm, scale, drop_p=0.0):
+    return AttnQ1Fn.apply(q1, q2, k1, k2, v, kpm, scale, drop_p)
 
 
 # ------------------------------------------------------------------------------------

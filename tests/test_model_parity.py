@@ -6,6 +6,7 @@ argmax temporal span bit-exact.  Gradients: 1e-3 relative to each tensor's max (
 * gpu variants: C1 (T=8, 224^2) against oracle AND the committed reference goldens; C3-shaped attention at
   T=64/448^2 is covered by tests/test_ops.py; a T=16/448^2 clip checks the full-resolution feature map here.
 """
+import math
 import os
 
 import numpy as np
@@ -164,6 +165,60 @@ def test_emu_tiny_clip_forward_backward():
     torch.manual_seed(0)
     g64 = _run_oracle(2, 64, 3, dtype=torch.float64)[4]
     _compare(_run_hip(dev, 2, 64, 3), _run_oracle(2, 64, 3), g64=g64)
+
+
+def _train_step(dev, seed, T=2, res=64, L=3, p_override=None):
+    """one train-mode (dropout active) forward + loss + backward of the tiny clip"""
+    from stcat_amd import ops
+    text = synth.synth_text(L)
+    model, criterion, wd = build_model(None, SyntheticText(text))
+    synth.fill_module_(model)
+    model.to(dev).train()
+    if p_override is not None:
+        for m in model.modules():
+            if hasattr(m, "dropout_p"):
+                m.dropout_p = p_override
+    ops.manual_seed(seed)
+    frames = synth.synth_frames(T, res).to(dev)
+    mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+    out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
+    keep = {k: out[k].detach().cpu().clone() for k in ("pred_boxes", "pred_sted", "weights")}  # the loss edits out
+    act, tb = synth.synth_targets(T)
+    losses = criterion(out, [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}], [T])
+    total = sum(losses[k] * wd[k] for k in losses)
+    total.backward()
+    grads = {n: q.grad.detach().cpu().clone() for n, q in model.named_parameters() if q.grad is not None}
+    return keep, total.item(), grads
+
+
+def _check_train_mode(dev):
+    o1, l1, g1 = _train_step(dev, seed=11)
+    o2, l2, g2 = _train_step(dev, seed=11)
+    o3, l3, _ = _train_step(dev, seed=12)
+    # same seed -> the same masks in forward AND backward (bitwise, up to the atomics of the split-K weight gradients)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert l1 == l2
+    for n in g1:
+        close(g2[n], g1[n], 1e-5, "replayed gradient " + n)
+    assert all(torch.isfinite(v).all() for v in g1.values()) and math.isfinite(l1)
+    assert not torch.equal(o1["pred_boxes"], o3["pred_boxes"]) and l1 != l3     # another seed, other masks
+    # dropout really acts on the heads' outputs (net_utils.py:24: p=0.3 after the LAST layer too): exact zeros appear
+    assert (o1["pred_sted"] == 0).any()
+    # train mode with p = 0 is the eval arithmetic
+    o0, l0, _ = _train_step(dev, seed=11, p_override=0.0)
+    model_eval = _run_hip_impl(dev, 2, 64, 3, with_backward=True)
+    close(o0["pred_boxes"], model_eval[0]["pred_boxes"], 1e-6, "p=0 train vs eval boxes")
+    assert abs(l0 - model_eval[1]["total"]) <= 1e-5 * max(1.0, abs(l0))
+
+
+def test_emu_train_mode_dropout():
+    _check_train_mode(use_emu())
+
+
+@pytest.mark.gpu
+def test_gpu_train_mode_dropout():
+    _check_train_mode(use_hip())
 
 
 @pytest.mark.gpu

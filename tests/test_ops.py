@@ -283,6 +283,108 @@ def _attn_q1(dev, big):
         _q1_case(dev, 7, 256, 8, True)
 
 
+
+# ---------------------------------------------------------------------------------------
+# train-mode dropout: the kernels' counter-based masks replayed in the fp32 reference
+# ---------------------------------------------------------------------------------------
+def _mask_of(drop_p, seed, offset, n):
+    import numpy as np
+    keep = ops.dropout_keep_mask(seed, offset, n, drop_p)
+    return torch.from_numpy(keep.astype(np.float32)) * float(np.float32(1.0 / (1.0 - float(np.float32(drop_p)))))
+
+
+def _dropout_elementwise(dev, n, with_res):
+    pdrop = 0.1
+    x, r, g = rnd(n, seed=1), rnd(n, seed=2), rnd(n, seed=3)
+    ops.manual_seed(1234, rank=3)
+    seed, off = ops.dropout_stream_state()
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True)
+    y = ops.dropout_add(xd, rd, pdrop) if with_res else ops.dropout(xd, pdrop)
+    y.backward(g.to(dev))
+    m = _mask_of(pdrop, seed, off, n)
+    ref = x * m + (r if with_res else 0.0)
+    assert torch.equal(y.detach().cpu(), ref), "dropout forward is not bit-identical to the host twin"
+    assert torch.equal(xd.grad.cpu(), g * m)
+    if with_res:
+        assert torch.equal(rd.grad.cpu(), g)
+    keep_rate = (m > 0).float().mean().item()
+    assert abs(keep_rate - (1 - pdrop)) < 4.0 * math.sqrt(pdrop * (1 - pdrop) / n) + 1e-3, keep_rate
+    # the stream advanced past this site: a second site gets a different mask
+    assert ops.dropout_stream_state()[1] >= off + n
+    y2 = ops.dropout(x.to(dev), pdrop)
+    assert not torch.equal((y2 != 0).cpu(), (m > 0))
+
+
+def _mha_dropout_case(dev, B, S, H, need_w, pdrop=0.25):
+    D = H * 32
+    SP = ((S + 31) // 32) * 32
+    qk, v = rnd(B, S, 2 * D, seed=1), rnd(B, S, D, seed=2)
+    scale = 32 ** -0.5
+    ops.manual_seed(77)
+    seed, off = ops.dropout_stream_state()
+    # counter layout of the kernels: ((b*H + h)*SP + key)*SP + query
+    m = _mask_of(pdrop, seed, off, B * H * SP * SP).view(B, H, SP, SP)[:, :, :S, :S].transpose(-1, -2)  # [B,H,q,k]
+    qkr, vr = qk.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    hd = 32
+    qh = (qkr[..., :D] * scale).view(B, S, H, hd).transpose(1, 2)
+    kh = qkr[..., D:].view(B, S, H, hd).transpose(1, 2)
+    vh = vr.view(B, S, H, hd).transpose(1, 2)
+    pd = (qh @ kh.transpose(-1, -2)).softmax(-1) * m
+    o_ref = (pd @ vh).transpose(1, 2).reshape(B, S, D)
+    w_ref = pd.mean(1)
+    go, gw = rnd(B, S, D, seed=3), rnd(B, S, S, seed=4)
+    loss = (o_ref * go).sum() + ((w_ref * gw).sum() if need_w else 0.0)
+    loss.backward()
+    qkd, vd = qk.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    o, w = ops.mha_self_packed(qkd, vd, None, scale, need_w, drop_p=pdrop)
+    l2 = (o * go.to(dev)).sum()
+    if need_w:
+        l2 = l2 + (w * gw.to(dev)).sum()
+    l2.backward()
+    tag = f"mha-dropout B{B} S{S} H{H} w{need_w}"
+    close(o, o_ref, TOL, tag + " out")
+    if need_w:
+        close(w, w_ref, TOL, tag + " weights")
+    close(qkd.grad, qkr.grad, TOL, tag + " dqk")
+    close(vd.grad, vr.grad, TOL, tag + " dv")
+
+
+def _q1_dropout_case(dev, B, S, H, pdrop=0.25):
+    D = H * 32
+    q1, k1, v = rnd(B, D, seed=1), rnd(B, S, D, seed=3), rnd(B, S, D, seed=5)
+    scale = 32 ** -0.5
+    ops.manual_seed(5)
+    seed, off = ops.dropout_stream_state()
+    m = _mask_of(pdrop, seed, off, B * H * S).view(B, H, S).transpose(1, 2)  # [B,S,H]
+    a1, b1, vv = [t.clone().requires_grad_(True) for t in (q1, k1, v)]
+    sc = (a1.view(B, 1, H, 32) * b1.view(B, S, H, 32)).sum(-1) * scale
+    pd = sc.softmax(1) * m
+    ref = (pd[..., None] * vv.view(B, S, H, 32)).sum(1).reshape(B, D)
+    go = rnd(B, D, seed=6)
+    ref.backward(go)
+    dl = [t.to(dev).requires_grad_(True) for t in (q1, k1, v)]
+    out = ops.attn_q1(dl[0], None, dl[1], None, dl[2], None, scale, drop_p=pdrop)
+    out.backward(go.to(dev))
+    tag = f"q1-dropout B{B} S{S}"
+    close(out, ref, TOL, tag + " out")
+    for t, r, nm in zip(dl, (a1, b1, vv), ("dq1", "dk1", "dv")):
+        close(t.grad, r.grad, TOL, tag + " " + nm)
+
+
+@both
+def _dropout(dev, big):
+    _dropout_elementwise(dev, 4096 + 3, with_res=True)
+    _dropout_elementwise(dev, 1024, with_res=False)
+    _mha_dropout_case(dev, 2, 37, 2, need_w=False)
+    _mha_dropout_case(dev, 1, 40, 2, need_w=True)
+    _q1_dropout_case(dev, 3, 21, 2)
+    if big:
+        _dropout_elementwise(dev, 13248 * 2048, with_res=False)
+        _mha_dropout_case(dev, 16, 207, 8, need_w=False)
+        _mha_dropout_case(dev, 1, 64, 8, need_w=True)
+        _q1_dropout_case(dev, 64, 206, 8)
+
 @both
 def _elementwise(dev, big):
     a, b, c = rnd(6, 256, seed=1), rnd(6, 256, seed=2), rnd(6, 256, seed=3)
