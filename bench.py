@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--eval-mode", action="store_true",
                     help="run the step with dropout off (the parity configuration); default is train mode, "
                          "dropout 0.1 / 0.3 active as in the reference's training loop")
+    ap.add_argument("--no-optim", action="store_true", help="skip the (untimed-in-metric) optimizer-tail timing")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
@@ -287,6 +288,32 @@ def main():
                  "ms_per_step": round(1e3 * dt_exact, 2)}
         _lib.set_mma_mode(args.mma)
 
+    # Optimizer tail (clip_grad_norm_ + AdamW + EMA, scripts/train_net.py:134-143): NOT part of the fwd+bwd metric;
+    # timed here on the gradients the last step left behind so the cost of the next stage is on record.
+    opt_tail = None
+    if world == 1 and not args.no_optim:
+        import copy
+        from stcat_amd import optim
+        named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+        groups = [{"params": [p for n, p in named if "vis_encoder" not in n and "temp_decoder" not in n]},
+                  {"params": [p for n, p in named if "vis_encoder" in n], "lr": 2e-5},
+                  {"params": [p for n, p in named if "temp_decoder" in n], "lr": 1e-4}]
+        opt = optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+        ema = copy.deepcopy(model)
+        numel = sum(p.numel() for _, p in named)
+        for _ in range(2):
+            opt.step(max_grad_norm=0.1, model_ema=ema, ema_decay=0.9998, model=model)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            opt.step(max_grad_norm=0.1, model_ema=ema, ema_decay=0.9998, model=model)
+        fence()
+        dt_opt = (time.perf_counter() - t1) / 5
+        opt_tail = {"ms": round(1e3 * dt_opt, 3), "parameters": numel, "launches": 2,
+                    "GB_per_s": round(numel * 40 / dt_opt / 1e9, 1),
+                    "note": "10 fp32 accesses per parameter (g twice); HBM-bound"}
+        del opt, ema
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, min(os.cpu_count() or 1, args.cpu_threads))
@@ -303,7 +330,8 @@ def main():
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",
                        "allreduce_bytes": reducer.message_bytes},
-            "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "kernels": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "optimizer_tail": opt_tail,
+            "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

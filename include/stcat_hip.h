@@ -149,6 +149,26 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
                       int B, int H, int S, int ldq, int ldk, int ldv, float scale, float drop_p, long drop_seed,
                       long drop_offset, void* stream);
 
+/* ---- optimizer tail (scripts/train_net.py:134-143) ------------------------------------------------ */
+/* Multi-tensor launches over a DEVICE table of entries
+ *   { float* p; const float* g; float* m; float* v; float* ema (may be NULL); long n; int group; int pad; }
+ * (stcat_optim_table_entry_bytes() == 56) cut into chunks: chunk c covers elements
+ * [chunk_off[c], chunk_off[c] + chunk) of table[chunk_tensor[c]]; chunk % 4 == 0.
+ * stcat_grad_sqnorm: *out_sq = sum over all tensors of |g|^2 (torch.nn.utils.clip_grad_norm_, first half).
+ * stcat_adamw_ema_step: clip coefficient min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) (max_norm <= 0: none),
+ *   torch.optim.AdamW update (engine/optimizer.py:25-55; lr / wd are HOST arrays indexed by entry.group,
+ *   rewritten by the schedule of engine/lr_scheduler.py:212-252 every step) and the EMA copy
+ *   w_ema = w_ema * decay + (1 - decay) * w (engine/optimizer.py:5-22) in one pass.  step counts from 1.
+ * stcat_ema_update: the EMA alone, for state that is not a trained parameter. */
+int stcat_optim_table_entry_bytes(void);
+int stcat_grad_sqnorm(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                      float* out_sq, void* stream);
+int stcat_adamw_ema_step(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                         const float* sqnorm, const float* lr, const float* wd, int n_groups, float beta1,
+                         float beta2, float eps, int step, float max_norm, float ema_decay, void* stream);
+int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                     float decay, void* stream);
+
 /* ---- live 2D temporal map (models/post_processor.py:30-53) -------------------------------------- */
 /* sted [b,T,2], durations [b] (device int32) -> out [b,2] device int32 (start_idx, end_idx), T <= 1024 */
 int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out, int b, int T, void* stream);

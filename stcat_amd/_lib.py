@@ -45,12 +45,17 @@ SIGNATURES: Dict[str, str] = {
     "stcat_attn_weights_mean": "ppiii" + "flls",
     "stcat_attn_q1_fwd": "pppppppp" + "iiiiiif" + "flls",
     "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "flls",
+    "stcat_grad_sqnorm": "pppiips",
+    "stcat_adamw_ema_step": "pppiipPPifffiffs",
+    "stcat_ema_update": "pppiifs",
+    "stcat_optim_table_entry_bytes": "",
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_debug_force_tile": "ii",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
+       "P": ctypes.c_void_p}  # P = HOST pointer (small by-value arrays)
 
 EW_ADD, EW_MUL, EW_SIGMOID, EW_TANH, EW_RELU, EW_INVSIG = 0, 1, 2, 3, 4, 5
 EW_SIGMOID_BWD, EW_TANH_BWD, EW_INVSIG_BWD, EW_ADD3, EW_AXPBY, EW_COPY = 6, 7, 8, 9, 10, 11

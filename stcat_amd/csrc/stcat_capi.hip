@@ -6,6 +6,7 @@
 
 #include "../../include/stcat_hip.h"
 #include "attention.h"
+#include "optim.h"
 #include "igemm.h"
 #include "igemm_bs.h"
 #include "pointwise.h"
@@ -493,6 +494,46 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset);
   STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+// ---- optimizer tail --------------------------------------------------------------------------------------
+int stcat_optim_table_entry_bytes(void) { return (int)sizeof(OptTensor); }
+
+int stcat_grad_sqnorm(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                      float* out_sq, void* stream) {
+  if (n_chunks <= 0 || chunk <= 0 || chunk % 4 != 0) return fail("grad_sqnorm: bad chunking (%d x %d)", n_chunks, chunk);
+  hipError_t e = hipMemsetAsync(out_sq, 0, sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return fail("grad_sqnorm: memset: %s", hipGetErrorString(e));
+  STCAT_LAUNCH(grad_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table,
+               chunk_tensor, chunk_off, chunk, out_sq);
+  return launch_status();
+}
+
+int stcat_adamw_ema_step(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                         const float* sqnorm, const float* lr, const float* wd, int n_groups, float beta1,
+                         float beta2, float eps, int step, float max_norm, float ema_decay, void* stream) {
+  if (n_chunks <= 0 || chunk <= 0 || chunk % 4 != 0) return fail("adamw: bad chunking (%d x %d)", n_chunks, chunk);
+  if (n_groups <= 0 || n_groups > STCAT_OPT_MAX_GROUPS) return fail("adamw: %d parameter groups (max %d)", n_groups,
+                                                                     STCAT_OPT_MAX_GROUPS);
+  if (step < 1) return fail("adamw: step counts from 1");
+  if (max_norm > 0.f && !sqnorm) return fail("adamw: clipping needs the squared gradient norm");
+  OptHyper h = {};
+  for (int i = 0; i < n_groups; ++i) { h.lr[i] = lr[i]; h.wd[i] = wd[i]; }  // lr / wd are HOST arrays
+  h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
+  h.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  h.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  h.max_norm = max_norm; h.ema_decay = ema_decay;
+  STCAT_LAUNCH(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table,
+               chunk_tensor, chunk_off, chunk, sqnorm, h);
+  return launch_status();
+}
+
+int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                     float decay, void* stream) {
+  if (n_chunks <= 0 || chunk <= 0) return fail("ema_update: bad chunking");
+  STCAT_LAUNCH(ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table, chunk_tensor,
+               chunk_off, chunk, decay);
   return launch_status();
 }
 

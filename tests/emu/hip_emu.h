@@ -37,6 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
+static inline const char* hipGetErrorString(hipError_t) { return "emulator"; }
+static inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) {
+  memset(p, value, bytes);
+  return hipSuccess;
+}
 
 extern "C" void stcat_emu_switch(void** from_sp, void* to_sp);
 

@@ -1,0 +1,147 @@
+"""Optimizer tail (clip_grad_norm_ + AdamW + EMA, scripts/train_net.py:134-143) through the C ABI against
+torch.optim.AdamW / torch.nn.utils.clip_grad_norm_ / the reference's update_ema arithmetic on CPU, plus the
+learning-rate schedule of engine/lr_scheduler.py:212-252 against known values."""
+import copy
+from types import SimpleNamespace as NS
+
+import torch
+from torch import nn
+
+from stcat_amd import optim
+from tests.backends import both, close
+
+
+class _Toy(nn.Module):
+    """parameter names hit all four groups of engine/optimizer.py:26-43; sizes cover the vector path, ragged tails,
+    several chunks and a frozen tensor"""
+
+    def __init__(self):
+        super().__init__()
+        self.vis_encoder = nn.Linear(300, 301)                      # 90 300 + 301 elements: > 1 chunk, ragged
+        self.text_encoder = nn.Linear(7, 5)
+        self.ground_decoder = nn.Module()
+        self.ground_decoder.temp_decoder = nn.Linear(16, 3)
+        self.rest = nn.Parameter(torch.randn(2, 65536 + 5))        # chunk boundary + tail
+        self.frozen = nn.Parameter(torch.randn(9), requires_grad=False)
+        self.unused = nn.Parameter(torch.randn(4))                  # never gets a gradient
+
+
+def _cfg():
+    return NS(SOLVER=NS(OPTIMIZER="adamw", BASE_LR=3e-4, VIS_BACKBONE_LR=2e-5, TEXT_LR=5e-5, TEMP_LR=1e-4,
+                        WEIGHT_DECAY=1e-4, MAX_GRAD_NORM=0.1, WARMUP_PROP=0.01, MAX_EPOCH=10,
+                        SCHEDULE=NS(TYPE="multistep_with_warmup", DROP_STEP=[8])),
+              MODEL=NS(EMA_DECAY=0.9998))
+
+
+def _fake_grads(model, step):
+    g = torch.Generator().manual_seed(100 + step)
+    out = {}
+    for n, p in model.named_parameters():
+        if p.requires_grad and n != "unused":
+            out[n] = torch.randn(p.shape, generator=g) * (10.0 if step == 1 else 0.01)   # clipped / not clipped
+    return out
+
+
+def _reference_run(cfg, steps, decay):
+    torch.manual_seed(0)
+    model = _Toy()
+    ema = copy.deepcopy(model)
+    named = dict(model.named_parameters())
+    groups = [{"params": [named["rest"], named["unused"]]},
+              {"params": [named["vis_encoder.weight"], named["vis_encoder.bias"]], "lr": cfg.SOLVER.VIS_BACKBONE_LR},
+              {"params": [named["text_encoder.weight"], named["text_encoder.bias"]], "lr": cfg.SOLVER.TEXT_LR},
+              {"params": [named["ground_decoder.temp_decoder.weight"], named["ground_decoder.temp_decoder.bias"]],
+               "lr": cfg.SOLVER.TEMP_LR}]
+    opt = torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    norms = []
+    for s in range(steps):
+        opt.zero_grad()
+        for n, g in _fake_grads(model, s).items():
+            named[n].grad = g.clone()
+        norms.append(torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.MAX_GRAD_NORM).item())
+        opt.step()
+        optim.adjust_learning_rate(cfg, opt, s, 1000)
+        with torch.no_grad():
+            msd = model.state_dict()
+            for k, v in ema.state_dict().items():
+                v.copy_(v * decay + (1.0 - decay) * msd[k])
+    return model, ema, norms
+
+
+@both
+def _fused_tail(dev, big):
+    cfg = _cfg()
+    decay = 0.9
+    steps = 4
+    ref_model, ref_ema, ref_norms = _reference_run(cfg, steps, decay)
+    torch.manual_seed(0)
+    model = _Toy().to(dev)
+    ema = copy.deepcopy(model)
+    opt = optim.make_optimizer(cfg, model)
+    assert [len(g["params"]) for g in opt.param_groups] == [2, 2, 2, 2]
+    named = dict(model.named_parameters())
+    for s in range(steps):
+        opt.zero_grad()
+        for n, g in _fake_grads(model, s).items():
+            named[n].grad = g.to(dev)
+        sq = opt.step(max_grad_norm=cfg.SOLVER.MAX_GRAD_NORM, model_ema=ema, ema_decay=decay, model=model)
+        assert abs(sq.sqrt().item() - ref_norms[s]) <= 1e-5 * ref_norms[s]
+        optim.adjust_learning_rate(cfg, opt, s, 1000)
+    for (n, p), (_, r) in zip(model.named_parameters(), ref_model.named_parameters()):
+        close(p, r, 2e-6, "parameter " + n)
+    for (n, p), (_, r) in zip(ema.named_parameters(), ref_ema.named_parameters()):
+        close(p, r, 2e-6, "ema " + n)
+    assert torch.equal(model.frozen.cpu(), ref_model.frozen) and torch.equal(model.unused.cpu(), ref_model.unused)
+    # checkpoint round trip of the moments
+    sd = opt.state_dict()
+    opt2 = optim.make_optimizer(cfg, model)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == steps and len(opt2.state) == len(opt.state)
+
+
+@both
+def _standalone_clip_and_ema(dev, big):
+    torch.manual_seed(1)
+    model = _Toy()
+    ref = copy.deepcopy(model)
+    for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+        if p.requires_grad and n != "unused":
+            r.grad = torch.randn_like(r) * 3
+    model = model.to(dev)
+    for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+        if r.grad is not None:
+            p.grad = r.grad.clone().to(dev)
+    n_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+    n_hip = optim.clip_grad_norm_(model.parameters(), 0.1)
+    assert abs(n_hip.item() - n_ref.item()) <= 1e-5 * n_ref.item()
+    for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
+        if r.grad is not None:
+            close(p.grad, r.grad, 2e-6, "clipped grad " + n)
+    ema, ema_ref = copy.deepcopy(model), copy.deepcopy(ref)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(1.0)
+        for p in ref.parameters():
+            p.add_(1.0)
+        for k, v in ema_ref.state_dict().items():
+            v.copy_(v * 0.75 + 0.25 * ref.state_dict()[k])
+    optim.update_ema(model, ema, 0.75)
+    for (n, p), (_, r) in zip(ema.named_parameters(), ema_ref.named_parameters()):
+        close(p, r, 1e-6, "standalone ema " + n)
+
+
+def test_lr_schedule_values():
+    cfg = _cfg()
+    opt = NS(param_groups=[{"lr": 0.0} for _ in range(4)])
+    total = 1000                                  # warmup = 10 steps, 100 steps per epoch
+    optim.adjust_learning_rate(cfg, opt, 5, total)
+    lrs = [g["lr"] for g in opt.param_groups]
+    assert lrs[0] == cfg.SOLVER.BASE_LR and lrs[1] == cfg.SOLVER.VIS_BACKBONE_LR
+    assert abs(lrs[2] - cfg.SOLVER.TEXT_LR * 0.5) < 1e-12 and abs(lrs[3] - cfg.SOLVER.TEMP_LR * 0.5) < 1e-12
+    optim.adjust_learning_rate(cfg, opt, 850, total)          # epoch 8 >= DROP_STEP -> x0.1; linear decay side
+    lrs = [g["lr"] for g in opt.param_groups]
+    assert abs(lrs[0] - cfg.SOLVER.BASE_LR * 0.1) < 1e-12
+    assert abs(lrs[2] - cfg.SOLVER.TEXT_LR * (150 / 990)) < 1e-12
+    cfg.SOLVER.SCHEDULE.TYPE = "multistep_with_warmup_all"
+    optim.adjust_learning_rate(cfg, opt, 2, total)
+    assert all(abs(g["lr"] - b * 0.2) < 1e-12 for g, b in zip(opt.param_groups, [3e-4, 2e-5, 5e-5, 1e-4]))
