@@ -304,14 +304,18 @@ def main():
         for _ in range(2):
             opt.step(max_grad_norm=0.1, model_ema=ema, ema_decay=0.9998, model=model)
         fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter()
+        e0.record()
         for _ in range(5):
             opt.step(max_grad_norm=0.1, model_ema=ema, ema_decay=0.9998, model=model)
+        e1.record()
         fence()
-        dt_opt = (time.perf_counter() - t1) / 5
-        opt_tail = {"ms": round(1e3 * dt_opt, 3), "parameters": numel, "launches": 2,
-                    "GB_per_s": round(numel * 40 / dt_opt / 1e9, 1),
-                    "note": "10 fp32 accesses per parameter (g twice); HBM-bound"}
+        dt_wall = (time.perf_counter() - t1) / 5
+        dt_opt = e0.elapsed_time(e1) / 5e3
+        opt_tail = {"ms": round(1e3 * dt_opt, 3), "wall_ms": round(1e3 * dt_wall, 3), "parameters": numel,
+                    "launches": 2, "GB_per_s": round(numel * 40 / dt_opt / 1e9, 1),
+                    "note": "10 fp32 accesses per parameter (g twice); HBM-bound; ms = device time (HIP events)"}
         del opt, ema
 
     cpu = None

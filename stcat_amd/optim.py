@@ -58,6 +58,16 @@ class _TensorTable:
         self.n_chunks = len(ct)
 
 
+def _dense(t: torch.Tensor) -> bool:
+    """element-wise kernels only need a gap-free buffer: row-major, or channels_last (the conv weights' OHWI)"""
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """same element order in memory (strides of size-1 dims are arbitrary and ignored)"""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
@@ -87,6 +97,9 @@ class AdamW:
         self.step_count = 0
         self._table = None
         self._sq = None
+        self._plist = [p for g in self.param_groups for p in g["params"]]
+        self._gkey = None
+        self._any = None
 
     def zero_grad(self, set_to_none: bool = True):
         for g in self.param_groups:
@@ -102,12 +115,14 @@ class AdamW:
             for p in g["params"]:
                 if p.grad is None:
                     continue
-                if not (p.is_contiguous() and p.grad.is_contiguous()):
-                    raise L.StcatHipError("optimizer tensors must be contiguous")
+                if not _dense(p) or not _same_layout(p.grad, p):
+                    raise L.StcatHipError("optimizer tensors must be dense and share one memory layout")
                 st = self.state.get(p)
                 if st is None:
                     st = self.state[p] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
                 e = ema_of.get(p) if ema_of else None
+                if e is not None and not _same_layout(e, p):
+                    raise L.StcatHipError("EMA tensor layout differs from its parameter")
                 rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              _ptr(e), p.numel(), gi))
         return rows
@@ -117,21 +132,26 @@ class AdamW:
         """One optimizer step.  max_grad_norm > 0 clips by the global norm first (train_net.py:136-137); with
         `model_ema` (and the `model` it shadows) the EMA weights are updated in the same launch
         (engine/optimizer.py:5-22).  Returns the squared gradient norm as a device scalar (no sync)."""
-        ema_of = None
-        if model_ema is not None:
-            if model is None:
-                raise ValueError("model_ema needs the model it tracks")
-            ema_sd = dict(model_ema.named_parameters())
-            ema_of = {p: ema_sd[n] for n, p in model.named_parameters() if n in ema_sd}
-        rows = self._rows(ema_of)
-        if not rows:
-            return None
-        any_p = next(p for g in self.param_groups for p in g["params"] if p.grad is not None)
-        dev = any_p.device
-        if self._table is None:
-            self._table = _TensorTable(dev)
-            self._sq = torch.zeros(1, device=dev)
-        self._table.update(rows)
+        plist = self._plist
+        # cheap staleness key: the gradient pointers (everything else in the table is stable between steps)
+        gkey = (id(model_ema),) + tuple(p.grad.data_ptr() if p.grad is not None else 0 for p in plist)
+        if gkey != self._gkey:
+            ema_of = None
+            if model_ema is not None:
+                if model is None:
+                    raise ValueError("model_ema needs the model it tracks")
+                ema_sd = dict(model_ema.named_parameters())
+                ema_of = {p: ema_sd[n] for n, p in model.named_parameters() if n in ema_sd}
+            rows = self._rows(ema_of)
+            if not rows:
+                return None
+            self._any = next(p for p in plist if p.grad is not None)
+            if self._table is None:
+                self._table = _TensorTable(self._any.device)
+                self._sq = torch.zeros(1, device=self._any.device)
+            self._table.update(rows)
+            self._gkey = gkey
+        any_p = self._any
         t = self._table
         stream = L.stream_of(any_p)
         self.step_count += 1
@@ -161,8 +181,7 @@ class AdamW:
             self.state[params[int(i)]] = {k: v.to(params[int(i)].device).clone() for k, v in st.items()}
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update(saved)
-        if self._table is not None:
-            self._table.key = None
+        self._gkey = None
 
 
 def make_optimizer(cfg, model, logger=None) -> AdamW:
@@ -239,8 +258,8 @@ def update_ema(model, model_ema, decay: float) -> None:
         if ema_v.dtype != torch.float32:
             ema_v.copy_(src)
             continue
-        if not (ema_v.is_contiguous() and src.is_contiguous()):
-            raise L.StcatHipError("update_ema: tensors must be contiguous")
+        if not _dense(ema_v) or not _same_layout(src, ema_v):
+            raise L.StcatHipError("update_ema: tensors must be dense and share one memory layout")
         rows.append((src.data_ptr(), 0, 0, 0, ema_v.data_ptr(), ema_v.numel(), 0))
         dev, any_t = ema_v.device, ema_v
     if not rows:
