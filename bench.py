@@ -61,7 +61,7 @@ def _flops(name, a):
     if name == "stcat_linear_fwd":
         return 2.0 * a[5] * a[6] * a[7]
     if name in ("stcat_linear_dgrad", "stcat_linear_wgrad"):
-        o = 5 if name == "stcat_linear_dgrad" else 3
+        o = 5 if name == "stcat_linear_dgrad" else 4
         return 2.0 * a[o] * a[o + 1] * a[o + 2]
     if name == "stcat_mha_self_fwd":
         B, H, S = a[6:9]

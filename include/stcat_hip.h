@@ -87,8 +87,9 @@ int stcat_linear_fwd(const float* x, const float* w, const float* bias, const fl
 /* dx[M,K] = g[M,N] . w[N,K] (+ add[M,K]);  K % 64 == 0, N % 16 == 0; wt = optional w^T [K][N] (weight_transpose) */
 int stcat_linear_dgrad(const float* g, const float* w, const float* add, const float* wt, float* dx, int M, int N,
                        int K, int ldg, int lddx, void* stream);
-/* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0 */
-int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, int K, int ldg, int ldx,
+/* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0.  db (may be NULL; caller-zeroed,
+ * needs ldg == N) += column sums of g — the bias gradient of the same nn.Linear, summed inside the launch */
+int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,
                        void* stream);
 /* narrow heads, N <= 16, K % 4 == 0 */
 int stcat_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K,

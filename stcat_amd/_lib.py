@@ -32,7 +32,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_sine_embed_bwd": "ppppis",
     "stcat_linear_fwd": "pppppiiiiiiiils",
     "stcat_linear_dgrad": "pppppiiiiis",
-    "stcat_linear_wgrad": "pppiiiiis",
+    "stcat_linear_wgrad": "ppppiiiiis",
     "stcat_small_linear_fwd": "ppppiiis",
     "stcat_small_linear_bwd": "ppppppiiis",
     "stcat_colsum": "pppiis",

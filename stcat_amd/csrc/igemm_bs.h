@@ -177,9 +177,9 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
 // (~33 B/clk/CU measured); with all loads clustered at the top of the iteration every wave of the CU queues
 // there before its first MFMA, and load time ADDS to matrix time instead of hiding under it.
 #ifdef STCAT_EXP_NOINTERLEAVE
-#define STCAT_BS_INTERLEAVE_VMEM
+#define STCAT_BS_INTERLEAVE
 #else
-#define STCAT_BS_INTERLEAVE_VMEM                                                                         \
+#define STCAT_BS_INTERLEAVE                                                                              \
   STCAT_UNROLL                                                                                           \
   for (int i_ = 0; i_ < 8; ++i_) {                                                                       \
     STCAT_SCHED_GROUP(0x008, 2);                                                                         \
@@ -194,13 +194,13 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
   for (int kt = 0; kt < nk; kt += 2) {                                                                   \
     STCAT_EXP_LOAD(LOAD(kt + 2, 0))                                                                      \
     STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[0], Bs[0]))                                                    \
-    STCAT_BS_INTERLEAVE_VMEM                                                                             \
+    STCAT_BS_INTERLEAVE                                                                                  \
     if (kt + 1 < nk) { STCAT_EXP_STORE(STORE(1, 1)) }                                                    \
     __syncthreads();                                                                                     \
     if (kt + 1 >= nk) break;                                                                             \
     STCAT_EXP_LOAD(LOAD(kt + 3, 1))                                                                      \
     STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[1], Bs[1]))                                                    \
-    STCAT_BS_INTERLEAVE_VMEM                                                                             \
+    STCAT_BS_INTERLEAVE                                                                                  \
     if (kt + 2 < nk) { STCAT_EXP_STORE(STORE(0, 0)) }                                                    \
     __syncthreads();                                                                                     \
   }
@@ -390,6 +390,10 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
       a_off[j][e] = i < BM * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + m0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
   }
   float4 ra[2][JA][4], rb[2][JB][4];
+  const bool do_rs = p.rowsum != nullptr && n0 == 0;  // first column tile of each row block owns the row sums
+  float4 rs[JA];
+  STCAT_UNROLL
+  for (int j = 0; j < JA; ++j) rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   // gathered B: pixel coordinates of this thread's first reduction row, advanced by 32 pixels per K-tile
   // without divisions (the loads are issued in increasing K-tile order)
   int g_nb[JB], g_oh[JB], g_ow[JB];
@@ -432,11 +436,39 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
       g_nb[j] = nb; g_oh[j] = oh; g_ow[j] = ow;                                                          \
     }                                                                                                    \
   }
-#define STCAT_BSW_STORE(SET, BUF) \
+#define STCAT_BSW_STORE(SET, BUF)                                                                        \
+  if (do_rs) { /* bias gradient rides along: column sums of dY from the registers already loaded */     \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < JA; ++j) {                                                                       \
+      STCAT_UNROLL                                                                                       \
+      for (int e = 0; e < 4; ++e) {                                                                      \
+        rs[j].x += ra[SET][j][e].x; rs[j].y += ra[SET][j][e].y;                                          \
+        rs[j].z += ra[SET][j][e].z; rs[j].w += ra[SET][j][e].w;                                          \
+      }                                                                                                  \
+    }                                                                                                    \
+  }                                                                                                      \
   STCAT_BS_STORE_O(As[BUF], BM, ra[SET]) STCAT_BS_STORE_O(Bs[BUF], BN, rb[SET])
   STCAT_BS_PIPELINE(STCAT_BSW_LOAD, STCAT_BSW_STORE)
 #undef STCAT_BSW_LOAD
 #undef STCAT_BSW_STORE
+  if (do_rs) {
+    STCAT_UNROLL
+    for (int j = 0; j < JA; ++j) {
+      const int i = t + 256 * j;
+      if (i < BM * 2) {  // wave-uniform (BM*2 is a multiple of 64)
+        float4 v = rs[j];
+        STCAT_UNROLL
+        for (int m = 1; m <= 4; m <<= 1) {  // the 8 k-groups of one row group are 8 consecutive lanes
+          v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m);
+          v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
+        }
+        if ((i & 7) == 0) {
+          float* dst = p.rowsum + m0 + (i >> 3) * 4;
+          atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        }
+      }
+    }
+  }
   STCAT_UNROLL
   for (int tn = 0; tn < TN; ++tn) {
     const int n = n0 + wn * TN * 32 + tn * 32 + l31;

@@ -336,7 +336,9 @@ int stcat_linear_dgrad(const float* g, const float* w, const float* add, const f
   return launch_dgrad(p, (hipStream_t)stream);
 }
 
-int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, int K, int ldg, int ldx,
+int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);
+
+int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,
                        void* stream) {
   if (N % 64 != 0 || K % 64 != 0) return fail("linear_wgrad: need N, K %% 64 == 0 (N=%d K=%d)", N, K);
   if (ldg % 4 != 0 || ldx % 4 != 0 || !aligned16(g) || !aligned16(x)) return fail("linear_wgrad: unaligned");
@@ -344,6 +346,13 @@ int stcat_linear_wgrad(const float* g, const float* x, float* dw, int M, int N, 
   p.A = g; p.B = x; p.C = dw; p.ldb = ldg; p.ldc = K;
   p.a_bytes = bytes_of((long)(M - 1) * ldg + N); p.b_bytes = bytes_of((long)(M - 1) * ldx + K);
   p.g = conv_geom_fwd(1, 1, K, ldx, 1, 1, 1, 1, 1, 0);
+  if (db) {
+    // split-bf16 kernels sum dY's columns from the operand registers they stage anyway; the fp32 kernels
+    // (reference mode) run the separate column-sum launch
+    if (g_mma_mode != 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu && ldg == N) p.rowsum = db;
+    else if (ldg != N) return fail("linear_wgrad: db needs a dense dY (ldg == N)");
+    else if (int rc = stcat_colsum(g, nullptr, db, M, N, stream)) return rc;
+  }
   return launch_wgrad(p, N, K, M, (hipStream_t)stream);
 }
 

@@ -182,10 +182,12 @@ class LinearFn(Function):
                 wt = weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
                 L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, L._ptr(wt), dx.data_ptr(), M, N, K, N,
                        K, st)
+            want_db = ctx.has_b and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 dw = _zeros(g, N, K)
-                L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), M, N, K, N, K, st)
-            if ctx.has_b and ctx.needs_input_grad[2]:
+                db = _zeros(g, N) if want_db else None  # bias gradient: summed inside the weight-gradient launch
+                L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, K, st)
+            elif want_db:
                 db = colsum(g)
         else:
             dx = _empty(g, M, K) if ctx.needs_input_grad[0] else None
