@@ -166,6 +166,10 @@ def main():
     ap.add_argument("--eval-mode", action="store_true",
                     help="run the step with dropout off (the parity configuration); default is train mode, "
                          "dropout 0.1 / 0.3 active as in the reference's training loop")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (stcat_amd/graph.py) instead of enqueuing it launch "
+                         "by launch from Python; measured SLOWER on ROCm 7.2 (hipGraphLaunch walks ~3500 nodes on the "
+                         "host: 99.5 vs 88.5 ms/step), so it is opt-in")
     ap.add_argument("--no-optim", action="store_true", help="skip the (untimed-in-metric) optimizer-tail timing")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
@@ -215,13 +219,21 @@ def main():
     plan = criterion.plan(targets, [T], dev)
     uniform_w = len({wd[k] for k in wd if k.startswith("loss_bbox")}) == 1  # aux copies share the main weights
 
-    def step():
-        reducer.zero_grad()
+    plan.num_boxes(dev)  # the loss's 1-element box-count all-reduce happens here, once per batch
+
+    def compute():
+        """forward + loss + backward of one video: no collectives, no host syncs (capturable)"""
+        ops.dropout_begin_step(dev)
         arena.reset()
         out = model(videos, ["synthetic"])
         losses = criterion(out, targets, [T], plan=plan)
         total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
         total.backward()
+        return total
+
+    def eager_step():
+        reducer.zero_grad()
+        total = compute()
         reducer.finish()
         return total
 
@@ -230,18 +242,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = eager_step
+    graphed = None
+    if args.graph:
+        # the whole step as ONE hipGraph launch (stcat_amd/graph.py); gradient exchange runs after each replay
+        from stcat_amd.graph import GraphedStep
+        # no eager autograd pass on the default stream before this point: AccumulateGrad nodes remember the stream
+        # they were created on, and default-stream ones break capture; GraphedStep warms up on a side stream
+        reducer.zero_grad()
+        reducer.defer(True)
+        graphed = GraphedStep(compute, dev, warmup=1)
+        reducer.bind_static_grads()
+
+        def step():
+            total = graphed.replay()
+            reducer.finish()
+            return total
+
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_s = time.perf_counter() - t0  # host time to ENQUEUE the steps (no sync): ~= elapsed means launch-bound
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     elapsed = dt.item()
 
+    if graphed is not None:  # the instrumented / side measurements below time individual launches: eager mode
+        reducer.defer(False)
+        step = eager_step
     roof, kernels = None, None
     if not args.no_profile:
         # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events
@@ -327,12 +360,14 @@ def main():
             "metric": "videos/sec fwd+bwd @ T=64 res=448 d=256", "value": round(world * args.steps / elapsed, 4),
             "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
                       "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",
+                       "launch": "one hipGraph per step" if args.graph else "eager (launch by launch)",
                        "allreduce_bytes": reducer.message_bytes},
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "optimizer_tail": opt_tail,
             "kernels": kernels,

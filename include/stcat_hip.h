@@ -118,8 +118,11 @@ enum {
  * index) — splitmix64 finaliser, see csrc/stcat_rng.h — so the same call on dY is the backward pass and no mask
  * is stored.  The attention entry points below take the same (drop_p, drop_seed, drop_offset) triple for the
  * dropout nn.MultiheadAttention / attention.py:381 applies to the softmax probabilities; drop_p = 0 disables it
- * (eval mode, and every parity test against the golden vectors). */
-int stcat_dropout(const float* x, const float* res, float* y, long n, float p, long seed, long offset, void* stream);
+ * (eval mode, and every parity test against the golden vectors).  base / drop_base (may be NULL) is a DEVICE
+ * int64 added to the offset when the kernel starts: the host advances it once per step with a device-side add, so
+ * a captured hipGraph replaying identical launch arguments still draws new masks each step. */
+int stcat_dropout(const float* x, const float* res, float* y, long n, float p, long seed, long offset,
+                  const long* base, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------------------- */
 /* torch.nn.MultiheadAttention core after the in-projection (modal_encoder.py:236; query_decoder.py:341,
@@ -128,27 +131,27 @@ int stcat_dropout(const float* x, const float* res, float* y, long n, float p, l
  * [B,H,Sp,Sp] (Sp = 32*ceil(S/32), key-major) for the backward pass / head-mean weights. */
 int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o,
                        float* pt, int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale,
-                       float drop_p, long drop_seed, long drop_offset, void* stream);
+                       float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
 /* out = forward output; dw (may be NULL) = gradient of the head-averaged weights [B,S,S] and then
  * corr = [B,H,S] scratch; dst = [B,H,Sp,Sp] scratch; dq/dk are [B,S,ldg], dv is [B,S,ldgv] */
 int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                        const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
                        int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
-                       float drop_p, long drop_seed, long drop_offset, void* stream);
+                       float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
 /* head-averaged weights [B,S,S] (need_weights=True; consumed at pipeline.py:84-85); in train mode these are
  * the DROPPED probabilities, as torch returns them */
 int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, float drop_p, long drop_seed,
-                            long drop_offset, void* stream);
+                            long drop_offset, const long* drop_base, void* stream);
 /* time-aligned cross-attention with ONE query per frame (query_decoder.py:386-417 via
  * grounding_model/attention.py:184-393; query_decoder.py:618-639): per (frame, head)
  * softmax(scale*(q1.k1 + q2.k2)) v, each part 32 wide; q2/k2 may be NULL.  P [B,H,S] is kept for backward. */
 int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
                       const unsigned char* kpm, float* out, float* P, int B, int H, int S, int ldq, int ldk,
-                      int ldv, float scale, float drop_p, long drop_seed, long drop_offset, void* stream);
+                      int ldv, float scale, float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
 int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
                       const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
                       int B, int H, int S, int ldq, int ldk, int ldv, float scale, float drop_p, long drop_seed,
-                      long drop_offset, void* stream);
+                      long drop_offset, const long* drop_base, void* stream);
 
 /* ---- optimizer tail (scripts/train_net.py:134-143) ------------------------------------------------ */
 /* Multi-tensor launches over a DEVICE table of entries

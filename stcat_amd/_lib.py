@@ -39,12 +39,12 @@ SIGNATURES: Dict[str, str] = {
     "stcat_layernorm_fwd": "pppppppiifs",
     "stcat_layernorm_bwd": "pppppppppiis",
     "stcat_ew": "ipppp" + "llffs",
-    "stcat_dropout": "ppplflls",
-    "stcat_mha_self_fwd": "ppppppiiiiiiif" + "flls",
-    "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "flls",
-    "stcat_attn_weights_mean": "ppiii" + "flls",
-    "stcat_attn_q1_fwd": "pppppppp" + "iiiiiif" + "flls",
-    "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "flls",
+    "stcat_dropout": "ppplfllps",
+    "stcat_mha_self_fwd": "ppppppiiiiiiif" + "fllps",
+    "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "fllps",
+    "stcat_attn_weights_mean": "ppiii" + "fllps",
+    "stcat_attn_q1_fwd": "pppppppp" + "iiiiiif" + "fllps",
+    "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "fllps",
     "stcat_grad_sqnorm": "pppiips",
     "stcat_adamw_ema_step": "pppiipPPifffiffs",
     "stcat_ema_update": "pppiifs",

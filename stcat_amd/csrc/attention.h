@@ -38,6 +38,7 @@ struct AttnParams {
 
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) mha_self_fwd_kernel(AttnParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
   constexpr int SP = NT * 32, KLD = 33;
   __shared__ __attribute__((aligned(16))) float Ks[SP * KLD];
   __shared__ __attribute__((aligned(16))) float Vs[SP * 32];
@@ -148,6 +149,7 @@ struct AttnBwdParams {
 // backward, phase 1: one wave per query tile -> dS (stored key-major, pre-multiplied by scale) and dQ
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
   constexpr int SP = NT * 32, KLD = 33;
   __shared__ __attribute__((aligned(16))) float Vs[SP * KLD];  // A operand of dP^T = V dO^T
   __shared__ __attribute__((aligned(16))) float Ks[SP * 32];   // B operand of dQ = dS K
@@ -223,6 +225,7 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_kernel(AttnBwdParams 
 // backward, phase 2: one wave per key tile -> dV = P^T dO, dK = (scale*dS)^T Q
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
   constexpr int SP = NT * 32;
   __shared__ __attribute__((aligned(16))) float dOs[SP * 32];
   __shared__ __attribute__((aligned(16))) float Qs[SP * 32];
@@ -281,6 +284,7 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams
 // head-averaged attention weights W[b][q][k] = mean_h P[b][h][q][k]  (nn.MultiheadAttention
 // need_weights=True; consumed only for the time decoder: pipeline.py:84-85)
 __global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H, int S, int SP, DropParams drop) {
+  drop = stcat_drop_resolve(drop);
   const long n = (long)B * S * S;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i % S), q = (int)((i / S) % S), b = (int)(i / ((long)S * S));
@@ -297,6 +301,7 @@ __global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H
 // head-averaged weights gradient; only the time decoder's self-attention has one)
 __global__ void attn_dw_corr_kernel(const float* Pt, const float* dW, float* corr, int B, int H, int S, int SP,
                                     DropParams drop) {
+  drop = stcat_drop_resolve(drop);
   const long n = (long)B * H * S;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i % S), h = (int)((i / S) % H), b = (int)(i / ((long)S * H));
@@ -337,6 +342,7 @@ struct AttnQ1Params {
 #define STCAT_Q1_MAXC 4  // S <= 256
 
 __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
+  p.drop = stcat_drop_resolve(p.drop);
   __shared__ float ps[4][STCAT_Q1_MAXC * 64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
   const int bh_raw = blockIdx.x * 4 + w;
@@ -403,6 +409,7 @@ __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
 }
 
 __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
+  p.drop = stcat_drop_resolve(p.drop);
   __shared__ float dss[4][STCAT_Q1_MAXC * 64];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
   const int bh_raw = blockIdx.x * 4 + w;

@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* w, f
 
 // y = res + dropout(x)   (res may be null; the same launch on dY is the backward of the x branch)
 __global__ void dropout_kernel(const float* x, const float* res, float* y, long n, DropParams d) {
+  d = stcat_drop_resolve(d);
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n) {
       float4 v = stcat_ld4(x + i);

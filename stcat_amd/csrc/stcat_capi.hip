@@ -412,12 +412,13 @@ int stcat_ew(int op, const float* a, const float* b, const float* c, float* out,
   return launch_status();
 }
 
-int stcat_dropout(const float* x, const float* res, float* y, long n, float p, long seed, long offset, void* stream) {
+int stcat_dropout(const float* x, const float* res, float* y, long n, float p, long seed, long offset,
+                  const long* base, void* stream) {
   if (n <= 0) return fail("dropout: n=%ld", n);
   if (!(p >= 0.f && p < 1.f)) return fail("dropout: p=%f outside [0,1)", (double)p);
   if (!aligned16(x) || !aligned16(y) || (res && !aligned16(res))) return fail("dropout: pointers must be 16-byte aligned");
   STCAT_LAUNCH(dropout_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, res, y, n,
-               stcat_make_drop(p, seed, offset));
+               stcat_make_drop(p, seed, offset, base));
   return launch_status();
 }
 
@@ -436,12 +437,12 @@ int stcat_dropout(const float* x, const float* res, float* y, long n, float p, l
 
 int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o,
                        float* pt, int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale,
-                       float drop_p, long drop_seed, long drop_offset, void* stream) {
+                       float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (S <= 0 || B <= 0 || H <= 0) return fail("mha_self_fwd: bad shape");
   if ((ldq | ldk | ldv) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v))
     return fail("mha_self_fwd: q/k/v must be 16-byte aligned with ld %% 4 == 0");
   AttnParams p = {q, k, v, o, pt, kpm, B, H, S, ldq, ldk, ldv, ldo, scale,
-                  stcat_make_drop(drop_p, drop_seed, drop_offset)};
+                  stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base)};
   const int nt = cdiv(S, 32);
   STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_fwd_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
   return launch_status();
@@ -450,7 +451,7 @@ int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const uns
 int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                        const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
                        int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
-                       float drop_p, long drop_seed, long drop_offset, void* stream) {
+                       float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (S <= 0 || B <= 0 || H <= 0) return fail("mha_self_bwd: bad shape");
   if ((ldq | ldk | ldv | ldo) % 4 != 0) return fail("mha_self_bwd: ld %% 4 != 0");
   if (dw && !corr) return fail("mha_self_bwd: dw given without corr scratch");
@@ -458,7 +459,7 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
   p.Q = q; p.K = k; p.V = v; p.dO = dout; p.Pt = pt; p.dW = dw; p.O = out; p.corr = corr; p.dSt = dst;
   p.dQ = dq; p.dK = dk; p.dV = dv; p.B = B; p.H = H; p.S = S;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldg = ldg; p.ldgv = ldgv; p.scale = scale;
-  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset);
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   const int nt = cdiv(S, 32);
   if (dw) {
     STCAT_LAUNCH(attn_dw_corr_kernel, dim3(grid_for((long)B * H * S, 256)), dim3(256), 0, (hipStream_t)stream, pt, dw,
@@ -472,22 +473,22 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
 }
 
 int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, float drop_p, long drop_seed,
-                            long drop_offset, void* stream) {
+                            long drop_offset, const long* drop_base, void* stream) {
   const int SP = cdiv(S, 32) * 32;
   STCAT_LAUNCH(attn_weights_mean_kernel, dim3(grid_for((long)B * S * S, 256)), dim3(256), 0, (hipStream_t)stream, pt, w,
-               B, H, S, SP, stcat_make_drop(drop_p, drop_seed, drop_offset));
+               B, H, S, SP, stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base));
   return launch_status();
 }
 
 int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
                       const unsigned char* kpm, float* out, float* P, int B, int H, int S, int ldq, int ldk,
-                      int ldv, float scale, float drop_p, long drop_seed, long drop_offset, void* stream) {
+                      int ldv, float scale, float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
   if ((ldq | ldk | ldv) % 4 != 0) return fail("attn_q1: ld %% 4 != 0");
   AttnQ1Params p = {};
   p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.kpm = kpm; p.out = out; p.P = P;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
-  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset);
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   STCAT_LAUNCH(attn_q1_fwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
@@ -495,13 +496,13 @@ int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const f
 int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
                       const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
                       int B, int H, int S, int ldq, int ldk, int ldv, float scale, float drop_p, long drop_seed,
-                      long drop_offset, void* stream) {
+                      long drop_offset, const long* drop_base, void* stream) {
   if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
   AttnQ1Params p = {};
   p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.P = const_cast<float*>(P); p.dout = dout;
   p.dq1 = dq1; p.dq2 = dq2; p.dk1 = dk1; p.dk2 = dk2; p.dv = dv;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
-  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset);
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }

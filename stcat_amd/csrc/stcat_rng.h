@@ -15,7 +15,17 @@ struct DropParams {
   float scale;                // 1 / (1 - p)
   unsigned long long seed;
   unsigned long long offset;  // first counter of this site
+  const unsigned long long* base;  // optional DEVICE word added to offset when the kernel starts: the per-step
+                                   // advance of the stream lives in HBM, so a captured hipGraph that replays the
+                                   // same launch arguments still draws fresh masks every step
 };
+
+// fold the device-resident base into the offset (call once at kernel entry)
+static __device__ __forceinline__ DropParams stcat_drop_resolve(DropParams d) {
+  if (d.thresh != 0u && d.base != nullptr) d.offset += *d.base;
+  d.base = nullptr;
+  return d;
+}
 
 static __device__ __forceinline__ unsigned stcat_rand32(unsigned long long seed, unsigned long long ctr) {
   unsigned long long z = seed + (ctr + 1ull) * 0x9E3779B97F4A7C15ull;
@@ -31,9 +41,10 @@ static __device__ __forceinline__ float stcat_drop_mul(const DropParams& d, unsi
   return stcat_rand32(d.seed, d.offset + idx) >= d.thresh ? d.scale : 0.f;
 }
 
-static inline DropParams stcat_make_drop(float p, long seed, long offset) {
+static inline DropParams stcat_make_drop(float p, long seed, long offset, const long* base) {
   DropParams d;
   d.thresh = 0u; d.scale = 1.f; d.seed = (unsigned long long)seed; d.offset = (unsigned long long)offset;
+  d.base = reinterpret_cast<const unsigned long long*>(base);
   if (p > 0.f) {
     const double t = (double)p * 4294967296.0;
     d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;

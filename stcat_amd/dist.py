@@ -70,6 +70,7 @@ class GradBucketReducer:
         self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=dev0) if (extra_numel and self.world > 1) else None
         self._extra_work = None
         self.extra_numel = extra_numel
+        self.deferred = False  # True: hooks do nothing, finish() reduces the (static) gradient tensors afterwards
 
     # ---- per step -------------------------------------------------------------------------------
     def zero_grad(self):
@@ -81,12 +82,27 @@ class GradBucketReducer:
             b["pending"] = len(b["params"])
             b["work"] = None
 
+    def defer(self, on: bool = True):
+        """Deferred mode for a hipGraph-captured step (stcat_amd/graph.py): gradient hooks launch nothing (a
+        collective must not be captured); after each replay finish() gathers the graph's static gradient tensors
+        (bind_static_grads) into the flat buckets and reduces them."""
+        self.deferred = on
+        if not on:
+            for b in self.buckets:
+                b.pop("static", None)
+
+    def bind_static_grads(self):
+        """call once, right after capture: remember the gradient tensors the captured backward writes"""
+        for b in self.buckets:
+            b["static"] = [p.grad for _, p in b["params"]]
+
     def _launch(self, b):
         if self.world > 1:
             srcs, dsts = [], []
-            for (n, p), v in zip(b["params"], b["views"]):
-                if p.grad is not None:
-                    srcs.append(p.grad)
+            grads = b.get("static") if self.deferred else [p.grad for _, p in b["params"]]
+            for g, v in zip(grads, b["views"]):
+                if g is not None:
+                    srcs.append(g)
                     dsts.append(v)
                 else:
                     v.zero_()
@@ -96,6 +112,8 @@ class GradBucketReducer:
         b["pending"] = -1
 
     def _on_grad(self, p):
+        if self.deferred:
+            return
         b = self.buckets[self._owner[p]]
         b["pending"] -= 1
         if b["pending"] == 0:
@@ -109,7 +127,7 @@ class GradBucketReducer:
         if self.extra is not None:
             self._extra_work = dist.all_reduce(self.extra, group=self.group, async_op=True)
         for b in self.buckets:
-            if b["pending"] >= 0:  # a parameter got no gradient this step: reduce what is there
+            if self.deferred or b["pending"] >= 0:  # (eager) a parameter got no gradient: reduce what is there
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()

@@ -406,32 +406,58 @@ _MASK64 = (1 << 64) - 1
 
 
 class _DropoutStream:
-    """(seed, running element counter) of this process.  Every dropout site of a step takes a fresh counter range
-    (csrc/stcat_rng.h); the backward pass replays the range saved by its forward.  DP ranks must seed differently
-    (manual_seed(seed, rank)), exactly as torch's per-process generators differ."""
+    """(seed, counter) of this process.  Every dropout site of a step takes a fresh counter range
+    (csrc/stcat_rng.h); the backward pass replays the range saved by its forward.  The counter has two parts:
+    a HOST offset that restarts at 0 every step (so a step always issues the same launch arguments) and a DEVICE
+    base advanced by STEP_SPAN at `begin_step()` with a device-side add — which is what lets a captured hipGraph
+    draw new masks on every replay.  DP ranks must seed differently (manual_seed(seed, rank)), exactly as torch's
+    per-process generators differ."""
+
+    STEP_SPAN = 1 << 36  # counters reserved per step (a C5 step uses ~2^33)
 
     def __init__(self):
         self.seed = 0x5DEECE66D
         self.offset = 0
+        self._base = {}
 
-    def take(self, numel: int):
+    def base(self, device) -> torch.Tensor:
+        b = self._base.get(device)
+        if b is None:
+            b = self._base[device] = torch.zeros(1, dtype=torch.int64, device=device)
+        return b
+
+    def take(self, numel: int, device):
         off = self.offset
-        self.offset = (off + ((numel + 3) // 4) * 4) & ((1 << 62) - 1)
-        return self.seed, off
+        self.offset = off + ((numel + 3) // 4) * 4
+        if self.offset > self.STEP_SPAN:
+            raise RuntimeError("dropout counter range of one step exhausted; call ops.dropout_begin_step()")
+        return self.seed, off, self.base(device).data_ptr()
+
+    def begin_step(self, device):
+        self.offset = 0
+        self.base(device).add_(self.STEP_SPAN)  # stream-ordered (and capturable): no host sync
 
 
 _dropout_stream = _DropoutStream()
 
 
 def manual_seed(seed: int, rank: int = 0) -> None:
-    """Seed the dropout stream of this process (counter restarts at 0)."""
+    """Seed the dropout stream of this process (counters restart at 0)."""
     z = (seed * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & _MASK64
     z ^= z >> 31
     _dropout_stream.seed = z & ((1 << 62) - 1)
     _dropout_stream.offset = 0
+    for b in _dropout_stream._base.values():
+        b.zero_()
+
+
+def dropout_begin_step(device) -> None:
+    """Call once at the top of every training step (inside the captured region when the step is a hipGraph)."""
+    _dropout_stream.begin_step(torch.device(device))
 
 
 def dropout_stream_state():
+    """(seed, host offset) — the device base is 0 until the first dropout_begin_step()"""
     return _dropout_stream.seed, _dropout_stream.offset
 
 
@@ -459,19 +485,19 @@ class DropoutFn(Function):
     def forward(ctx, x, res, p):
         x = _c(x)
         r = _c(res) if res is not None else None
-        seed, off = _dropout_stream.take(x.numel())
+        seed, off, base = _dropout_stream.take(x.numel(), x.device)
         y = torch.empty_like(x)
-        L.call("stcat_dropout", x.data_ptr(), L._ptr(r), y.data_ptr(), x.numel(), float(p), seed, off, L.stream_of(x))
-        ctx.drop = (float(p), seed, off)
+        L.call("stcat_dropout", x.data_ptr(), L._ptr(r), y.data_ptr(), x.numel(), float(p), seed, off, base,
+               L.stream_of(x))
+        ctx.drop = (float(p), seed, off, base)
         ctx.has_res = res is not None
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = _c(g)
-        p, seed, off = ctx.drop
         dx = torch.empty_like(g)
-        L.call("stcat_dropout", g.data_ptr(), None, dx.data_ptr(), g.numel(), p, seed, off, L.stream_of(g))
+        L.call("stcat_dropout", g.data_ptr(), None, dx.data_ptr(), g.numel(), *ctx.drop, L.stream_of(g))
         return dx, (g if ctx.has_res else None), None
 
 
@@ -511,9 +537,9 @@ class MhaSelfFn(Function):
         SP = ((S + 31) // 32) * 32
         o = _empty(v, B, S, D)
         pt = _empty(v, B, H, SP, SP)
-        drop = (0.0, 0, 0)
+        drop = (0.0, 0, 0, None)
         if drop_p > 0.0:  # dropout on the probabilities (nn.MultiheadAttention(dropout=p) in train mode)
-            drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP)
+            drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP, v.device)
         L.call("stcat_mha_self_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), pt.data_ptr(),
                B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, *drop, L.stream_of(v))
         wts = None
@@ -585,9 +611,9 @@ class AttnQ1Fn(Function):
         kp = _c(kpm.to(torch.uint8)) if kpm is not None else None
         out = _empty(v, B, D)
         P = _empty(v, B, H, S)
-        drop = (0.0, 0, 0)
+        drop = (0.0, 0, 0, None)
         if drop_p > 0.0:
-            drop = (float(drop_p),) + _dropout_stream.take(B * H * S)
+            drop = (float(drop_p),) + _dropout_stream.take(B * H * S, v.device)
         ctx.drop = drop
         L.call("stcat_attn_q1_fwd", q1.data_ptr(), L._ptr(q2), k1.data_ptr(), L._ptr(k2), v.data_ptr(), L._ptr(kp),
                out.data_ptr(), P.data_ptr(), B, H, S, D, ldk, ldv, scale, *drop, L.stream_of(v))

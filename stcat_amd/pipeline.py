@@ -124,6 +124,7 @@ class LossPlan:
         self.bounds = bounds
         self.rows = torch.tensor(rows, dtype=torch.long).to(device, non_blocking=True)
         self.num_boxes_local = float(sum(len(t["boxs"]) for t in targets))
+        self._num_boxes = None
         time_mask = torch.zeros(b, T, dtype=torch.bool)
         positive = torch.zeros(b, T, dtype=torch.bool)
         weight = torch.full((b, T), eos_coef)
@@ -146,6 +147,19 @@ class LossPlan:
         self.dist = torch.stack(dists, dim=-1).to(device)                       # [b,T,2]
         self.tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).to(device)
         self.actioness = torch.stack([t["actioness"] for t in targets]).float().to(device)
+
+    def num_boxes(self, dev):
+        """criterion.py:175-178: box count averaged over ranks, clamped to >= 1.  It depends on the targets only,
+        so the 1-element all-reduce runs ONCE here, when the plan is first used — not inside every loss
+        evaluation (which keeps the loss free of collectives and capturable in a hipGraph)."""
+        if self._num_boxes is None:
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                nb = torch.as_tensor([self.num_boxes_local], dtype=torch.float, device=dev)
+                torch.distributed.all_reduce(nb)
+                self._num_boxes = torch.clamp(nb / torch.distributed.get_world_size(), min=1)  # device: no sync
+            else:
+                self._num_boxes = max(self.num_boxes_local, 1.0)
+        return self._num_boxes
 
 
 class VideoSTGLoss(nn.Module):
@@ -173,13 +187,7 @@ class VideoSTGLoss(nn.Module):
         boxes = torch.stack([l["pred_boxes"] for l in layers])[:, plan.rows]        # [nl, nbox, 4]
         for i, l in enumerate(layers):
             l["pred_boxes"] = boxes[i]
-        num_boxes = plan.num_boxes_local
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=dev)
-            torch.distributed.all_reduce(nb)                                         # criterion.py:175-177
-            num_boxes = torch.clamp(nb / torch.distributed.get_world_size(), min=1)  # stays on device: no sync
-        else:
-            num_boxes = max(num_boxes, 1.0)
+        num_boxes = plan.num_boxes(dev)
         vec = {}
         if "boxes" in self.losses:
             tgt = plan.tgt_boxes[None].expand(nl, -1, -1)

@@ -314,6 +314,12 @@ def _dropout_elementwise(dev, n, with_res):
     assert ops.dropout_stream_state()[1] >= off + n
     y2 = ops.dropout(x.to(dev), pdrop)
     assert not torch.equal((y2 != 0).cpu(), (m > 0))
+    # a new step restarts the host offset at 0 and advances the DEVICE base: same launch arguments, new mask
+    ops.dropout_begin_step(dev)
+    assert ops.dropout_stream_state()[1] == 0
+    y3 = ops.dropout(x.to(dev), pdrop)
+    m3 = _mask_of(pdrop, seed, ops._DropoutStream.STEP_SPAN, n)
+    assert torch.equal(y3.cpu(), x * m3)
 
 
 def _mha_dropout_case(dev, B, S, H, need_w, pdrop=0.25):
