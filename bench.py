@@ -78,6 +78,8 @@ def _pmc_traffic(entry: str, mma: str):
     x2 per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read from inside the process, hence the file."""
     import glob
     fam = {"stcat_conv_fwd": "_fwd_kernel", "stcat_conv_dgrad": "_dgrad_kernel", "stcat_conv_wgrad": "_wgrad_kernel"}.get(entry)
+    if entry.startswith("igemm_bs_fwd_kernel"):
+        fam = "_fwd_kernel"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*hbm_traffic*{mma}*.json")))
     if not fam or not files:
         return None
@@ -288,8 +290,16 @@ def main():
         kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                        "tflops": (round(v["flop"] / v["ms"] / 1e9, 2) if v["flop"] and v["ms"] else None)}
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        dom = max((k for k in agg if agg[k]["flop"] > 0), key=lambda k: agg[k]["ms"])
-        d = agg[dom]
+        # dominant KERNEL: in the split-bf16 modes the conv forward and the conv data gradient (pre-transposed
+        # weights) are the same device kernel, igemm_bs_fwd_kernel<128,128,NS> — price them together
+        fam = dict(agg)
+        if args.mma != "f32" and "stcat_conv_fwd" in agg and "stcat_conv_dgrad" in agg:
+            a, b = agg["stcat_conv_fwd"], agg["stcat_conv_dgrad"]
+            fam = {k: v for k, v in agg.items() if k not in ("stcat_conv_fwd", "stcat_conv_dgrad")}
+            fam["igemm_bs_fwd_kernel (stcat_conv_fwd + stcat_conv_dgrad)"] = {
+                "launches": a["launches"] + b["launches"], "ms": a["ms"] + b["ms"], "flop": a["flop"] + b["flop"]}
+        dom = max((k for k in fam if fam[k]["flop"] > 0), key=lambda k: fam[k]["ms"])
+        d = fam[dom]
         ach = d["flop"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
         # roofline in ISSUED matrix flops: algorithmic flops x (1 | 3 | 6) against the pipe that executes them
         mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6}[args.mma]
