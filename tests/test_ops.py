@@ -58,6 +58,11 @@ def _linear(dev, big):
     _linear_case(dev, 130, 128, 128, relu=False, res=False, tile=(128, 128))
     _linear_case(dev, 130, 128, 64, relu=True, res=True, tile=(128, 64))
     _linear_case(dev, 65, 192, 64, relu=False, res=True, tile=(64, 64))
+    # decoder-sized launches (M <= 64 rows of frame queries), ragged M, fused bias + residual + ReLU
+    _linear_case(dev, 64, 256, 256, relu=False, res=False)
+    _linear_case(dev, 37, 64, 512, relu=True, res=True)
+    _linear_case(dev, 8, 512, 64, relu=True, res=False)
+    _linear_case(dev, 2, 128, 320, relu=False, res=True)
     if big:
         _linear_case(dev, 13248, 512, 256, relu=False, res=False)
         _linear_case(dev, 13248, 2048, 256, relu=True, res=False)
