@@ -93,6 +93,15 @@ def _pmc_traffic(entry: str, mma: str):
             "note": "128-wide tiles of the family (the conv launches); PMC, separate passes"}
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+
+
 class LaunchProfiler:
     """Wraps _lib.call with a pair of HIP events per launch (same stream as the launch)."""
 
@@ -189,7 +198,15 @@ def main():
     local = min(local, torch.cuda.device_count() - 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # STCAT_FORCE_COMM=1: run the complete RCCL path (process group, barriers, bucketed async all-reduce, the
+    # loss's box-count all-reduce) even with ONE rank — the only way to exercise it on a 1-GPU box
+    force_comm = bool(os.environ.get("STCAT_FORCE_COMM")) and world == 1
+    if force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -208,7 +225,7 @@ def main():
         ops.manual_seed(20260929, rank)
     synth.fill_module_(model)
     model.to(dev)
-    reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0)
+    reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0, force_comm=force_comm)
     arena = ops.enable_zero_arena(dev, 120_000_000)  # weight-gradient accumulators etc.: one memset per step
 
     frames = synth.synth_frames(T, res, seed=1000 * 3 + rank).to(dev)
@@ -239,8 +256,10 @@ def main():
         reducer.finish()
         return total
 
+    comm = world > 1 or force_comm
+
     def fence():
-        if world > 1:
+        if comm:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -270,7 +289,7 @@ def main():
     host_s = time.perf_counter() - t0  # host time to ENQUEUE the steps (no sync): ~= elapsed means launch-bound
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
-    if world > 1:
+    if comm:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     elapsed = dt.item()
 
@@ -314,7 +333,7 @@ def main():
         mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)
         roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
                                     "gflop_per_step": round(mm / 1e9, 1)}
-    if world > 1:
+    if comm:
         dist.barrier()
 
     exact = None
@@ -362,7 +381,7 @@ def main():
         del opt, ema
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N=1 only: other ranks would idle at the barrier
         cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, min(os.cpu_count() or 1, args.cpu_threads))
 
     if rank == 0:
@@ -382,9 +401,17 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "optimizer_tail": opt_tail,
             "kernels": kernels,
         }
-        print(json.dumps(line))
-    if world > 1:
+    # The JSON line must be the LAST thing on stdout.  RCCL writes a version banner through C stdio, which is
+    # block-buffered when stdout is a pipe and would otherwise be flushed at process exit, AFTER the line: flush
+    # it on every rank, tear the process group down, and only then print.
+    _flush_c_stdio()
+    if comm:
+        dist.barrier()
         dist.destroy_process_group()
+        _flush_c_stdio()
+    if rank == 0:
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -30,11 +30,15 @@ def live_trainable(named_params):
 
 
 class GradBucketReducer:
-    def __init__(self, model: torch.nn.Module, bucket_mb: float = 128.0, process_group=None, extra_numel: int = 0):
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 128.0, process_group=None, extra_numel: int = 0,
+                 force_comm: bool = False):
         """extra_numel: a dummy tail bucket (e.g. 124.6 M elements to emulate the reference's RoBERTa gradients
         in the message size) — reduced with the rest, never read."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # comm: gather into flat buckets and all-reduce.  force_comm keeps that path on with a single rank
+        # (a 1-GPU box can then exercise the real RCCL calls; the mean over 1 rank is the identity)
+        self.comm = self.world > 1 or (force_comm and dist.is_initialized())
         params = live_trainable(model.named_parameters())[::-1]  # reverse registration ~ readiness order
         self.params = [p for _, p in params]
         cap = int(bucket_mb * (1 << 20) // 4)
@@ -52,11 +56,11 @@ class GradBucketReducer:
         for bi, b in enumerate(self.buckets):
             dev = b["params"][0][1].device
             # the flat communication buffer only exists when there is somebody to talk to
-            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev) if self.world > 1 else None
+            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev) if self.comm else None
             b["views"] = []
             off = 0
             for n, p in b["params"]:
-                if self.world > 1:
+                if self.comm:
                     view = b["flat"][off:off + p.numel()]
                     # keep the parameter's memory format (conv weights are channels_last)
                     cl = p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
@@ -67,7 +71,7 @@ class GradBucketReducer:
             b["pending"] = len(b["params"])
             b["work"] = None
         dev0 = self.buckets[0]["params"][0][1].device
-        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=dev0) if (extra_numel and self.world > 1) else None
+        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=dev0) if (extra_numel and self.comm) else None
         self._extra_work = None
         self.extra_numel = extra_numel
         self.deferred = False  # True: hooks do nothing, finish() reduces the (static) gradient tensors afterwards
@@ -97,7 +101,7 @@ class GradBucketReducer:
             b["static"] = [p.grad for _, p in b["params"]]
 
     def _launch(self, b):
-        if self.world > 1:
+        if self.comm:
             srcs, dsts = [], []
             grads = b.get("static") if self.deferred else [p.grad for _, p in b["params"]]
             for g, v in zip(grads, b["views"]):
@@ -122,7 +126,7 @@ class GradBucketReducer:
     def finish(self):
         """Block the current stream until every bucket is reduced and averaged; afterwards every live
         parameter's .grad is (a view of) the averaged gradient."""
-        if self.world == 1:
+        if not self.comm:
             return
         if self.extra is not None:
             self._extra_work = dist.all_reduce(self.extra, group=self.group, async_op=True)

@@ -26,3 +26,22 @@ def test_bench_two_ranks_gloo():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "dp2" and d["roofline"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_single_rank_and_json_is_last_line():
+    """STCAT_FORCE_COMM=1 drives the complete RCCL path (process group on the device, barriers, bucketed async
+    all-reduce + wait + mean, the loss's box-count all-reduce) with one rank — what a 1-GPU box can check of the
+    N>1 configuration — and the bench line must be the LAST stdout line although RCCL prints a banner through
+    C stdio (flushed at exit when stdout is a pipe)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, STCAT_FORCE_COMM="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env.pop("STCAT_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "C1",
+           "--no-cpu-baseline", "--no-exact", "--no-optim"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    d = json.loads(last)                       # raises if anything (e.g. the RCCL banner) follows the line
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["allreduce_bytes"] > 3e8
