@@ -277,6 +277,17 @@ def test_gpu_c2_forward():
 
 
 @pytest.mark.gpu
+def test_gpu_c3_full_size_forward():
+    """The benchmark configuration itself (BASELINE configs[2]: T=64, 448x448, L=10, S=207) in the bench's
+    arithmetic (bf16x3): forward + PostProcess against the CPU oracle at FULL size — outputs within 1e-3,
+    temporal span bit-exact.  (The oracle's forward takes ~15 s on the GPU box's host cores.)"""
+    dev = use_hip()
+    T, res, L = synth.CONFIGS["C3"]
+    _compare(_run_hip(dev, T, res, L, with_backward=False, mma="bf16x3"), _run_oracle(T, res, L, with_backward=False),
+             with_backward=False)
+
+
+@pytest.mark.gpu
 def test_gpu_c5_shaped_clip_forward():
     """Long-query stress shape: 40 text tokens at 448x448 -> S = 237 tokens per frame (8 key tiles); T=12 keeps the
     CPU oracle in seconds (the per-frame arithmetic is identical at T=128)."""
