@@ -126,8 +126,10 @@ int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
   const bool big = (rows % 128 == 0) && (p.g.C % 128 == 0) && g_force_bm != 64;
   const int BM = big ? 128 : 64, BN = big ? 128 : 64;
   const int tiles = (rows / BM) * (cols / BN);
-  int nsplit = cdiv(1024, tiles);
-  const int max_split = cdiv(red, 64);
+  // split the reduction so that the grid is at most 1024 workgroups = two full rounds of the 512 resident slots
+  // (2 per CU): rounding UP here put 1044 blocks on the layer3 3x3 conv — a third, almost empty round
+  int nsplit = 1024 / tiles;
+  const int max_split = cdiv(red, 256);  // at least 8 K-tiles per workgroup: shorter loops are all prologue + atomics
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   int chunk = cdiv(red, nsplit);
