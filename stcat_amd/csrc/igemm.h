@@ -24,7 +24,20 @@ struct IgemmGeom {
   int OH, OW;              // spatial extent of the row index space (m -> nb, oh, ow)
   int KH, KW;
   int mul, off, sgn, div;  // h = oh*mul + off + kh*sgn; if div>1: need h%div==0, then h/=div
+  unsigned mg_ow, sh_ow, mg_ohw, sh_ohw;  // multiply-shift constants for m / OW and m / (OH*OW)  (stcat_fastdiv)
 };
+
+// floor(n / d) for 0 <= n < 2^31 as one 32x32->64 multiply and a shift: mg = floor(2^(31+sh) / d) + 1,
+// sh = ceil(log2 d)  (Granlund & Montgomery).  The host fills (mg, sh) with stcat_fastdiv_magic.
+static __device__ __forceinline__ int stcat_fastdiv(int n, unsigned mg, unsigned sh) {
+  return (int)(((unsigned long long)(unsigned)n * mg) >> (31u + sh));
+}
+static inline void stcat_fastdiv_magic(int d, unsigned* mg, unsigned* sh) {
+  unsigned s = 0;
+  while ((1ll << s) < (long long)d) ++s;
+  *sh = s;
+  *mg = (unsigned)(((1ull << (31 + s)) / (unsigned long long)d) + 1ull);
+}
 
 struct IgemmParams {
   const float* A;

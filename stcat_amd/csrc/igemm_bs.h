@@ -394,17 +394,9 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
   float4 rs[JA];
   STCAT_UNROLL
   for (int j = 0; j < JA; ++j) rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // gathered B: pixel coordinates of this thread's first reduction row, advanced by 32 pixels per K-tile
-  // without divisions (the loads are issued in increasing K-tile order)
-  int g_nb[JB], g_oh[JB], g_ow[JB];
-  STCAT_UNROLL
-  for (int j = 0; j < JB; ++j) {
-    const int m = red0 + ((t + 256 * j) & 7) * 4;
-    g_nb[j] = m / ohw;
-    const int rem = m - g_nb[j] * ohw;
-    g_oh[j] = rem / g.OW;
-    g_ow[j] = rem - g_oh[j] * g.OW;
-  }
+  // Gathered B: the pixel coordinates of a thread's 4 consecutive reduction rows come from two multiply-shift
+  // divisions per K-tile and carry with selects — no branch anywhere in the load, so it shares a basic block with
+  // the MFMAs and the scheduler can spread the loads between them (STCAT_BS_INTERLEAVE).
 #define STCAT_BSW_LOAD(KT, SET)                                                                          \
   {                                                                                                      \
     const int mbase = red0 + (KT) * BK;                                                                  \
@@ -419,21 +411,26 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < JB; ++j) {                                                                       \
       const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;                                          \
-      int nb = g_nb[j], oh = g_oh[j], ow = g_ow[j];                                                      \
+      const int mfirst = mbase + kgrp * 4;                                                               \
+      int nb = stcat_fastdiv(mfirst, g.mg_ohw, g.sh_ohw);                                                \
+      const int rem = mfirst - nb * ohw;                                                                 \
+      int oh = stcat_fastdiv(rem, g.mg_ow, g.sh_ow);                                                     \
+      int ow = rem - oh * g.OW;                                                                          \
       STCAT_UNROLL                                                                                       \
       for (int e = 0; e < 4; ++e) {                                                                      \
-        const int m = mbase + kgrp * 4 + e;                                                              \
-        long pix = -1;                                                                                   \
-        if (m < red1 && i < BN * 2) pix = stcat_gather_pix(g, nb, oh * g.mul + g.off, ow * g.mul + g.off, kh, kw); \
-        rb[SET][j][e] = stcat_buf_ld4(bufB, pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (ci0 + rowgrp * 4) * 4, 0u); \
-        if (++ow == g.OW) { ow = 0; if (++oh == g.OH) { oh = 0; ++nb; } }                                \
+        const int h = oh * g.mul + g.off + kh, w = ow * g.mul + g.off + kw;                              \
+        const bool ok = (mfirst + e < red1) & (i < BN * 2) & ((unsigned)h < (unsigned)g.H) &             \
+                        ((unsigned)w < (unsigned)g.W);                                                   \
+        const unsigned voff = (unsigned)(((nb * g.H + h) * g.W + w) * g.ld + ci0 + rowgrp * 4) * 4u;     \
+        rb[SET][j][e] = stcat_buf_ld4(bufB, ok ? voff : STCAT_BUF_OOB, 0u);                              \
+        ++ow;                                                                                            \
+        const bool c1 = ow == g.OW;                                                                      \
+        ow = c1 ? 0 : ow;                                                                                \
+        oh += c1 ? 1 : 0;                                                                                \
+        const bool c2 = oh == g.OH;                                                                      \
+        oh = c2 ? 0 : oh;                                                                                \
+        nb += c2 ? 1 : 0;                                                                                \
       }                                                                                                  \
-      /* advance this thread's first row by BK = 32 pixels for the next K-tile */                        \
-      ow = g_ow[j] + BK;                                                                                 \
-      oh = g_oh[j];                                                                                      \
-      nb = g_nb[j];                                                                                      \
-      while (ow >= g.OW) { ow -= g.OW; if (++oh == g.OH) { oh = 0; ++nb; } }                             \
-      g_nb[j] = nb; g_oh[j] = oh; g_ow[j] = ow;                                                          \
     }                                                                                                    \
   }
 #define STCAT_BSW_STORE(SET, BUF)                                                                        \

@@ -160,6 +160,8 @@ IgemmGeom conv_geom_fwd(int H, int W, int C, int ld, int OH, int OW, int KH, int
   IgemmGeom g;
   g.H = H; g.W = W; g.C = C; g.ld = ld; g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW;
   g.mul = stride; g.off = -pad; g.sgn = 1; g.div = 1;
+  stcat_fastdiv_magic(OW, &g.mg_ow, &g.sh_ow);
+  stcat_fastdiv_magic(OH * OW, &g.mg_ohw, &g.sh_ohw);
   return g;
 }
 }  // namespace
