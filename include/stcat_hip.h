@@ -128,7 +128,8 @@ int stcat_dropout(const float* x, const float* res, float* y, long n, float p, l
 /* torch.nn.MultiheadAttention core after the in-projection (modal_encoder.py:236; query_decoder.py:341,
  * 604-610): per (batch, head) softmax(scale * q k^T + key_padding) v with head dim 32, S <= 256.
  * q/k/v/o are [B,S,ld*] with head h at column h*32.  pt receives the probabilities as
- * [B,H,Sp,Sp] (Sp = 32*ceil(S/32), key-major) for the backward pass / head-mean weights. */
+ * [B,H,Sp,Sp] (Sp = 32*ceil(S/32), key-major) for the backward pass / head-mean weights; pt = NULL skips the
+ * 103 MB-per-layer store (inference: nothing reads it). */
 int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o,
                        float* pt, int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale,
                        float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);

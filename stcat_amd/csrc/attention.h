@@ -26,7 +26,7 @@ struct AttnParams {
   const float* K;
   const float* V;
   float* O;          // [B][S][ldo]
-  float* Pt;         // [B][H][Sp][Sp] probabilities, key-major
+  float* Pt;         // [B][H][Sp][Sp] probabilities, key-major; null = do not keep them (inference)
   const unsigned char* kpm;  // [B][S], 1 = padded key (-> -inf), or null
   int B, H, S;
   int ldq, ldk, ldv, ldo;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64 * NT) mha_self_fwd_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const float pr = sc[kt][r] * inv;
-      Ptg[(long)key * SP + q] = pr;
+      if (p.Pt) Ptg[(long)key * SP + q] = pr;  // the stash exists for backward / head-mean weights only
       const float pd = pr * stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
       o = STCAT_MFMA_32x32x2(pd, Vs[key * 32 + l31], o);
     }

@@ -536,18 +536,21 @@ class MhaSelfFn(Function):
             kp = _c(kpm.to(torch.uint8))
         SP = ((S + 31) // 32) * 32
         o = _empty(v, B, S, D)
-        pt = _empty(v, B, H, SP, SP)
+        # probabilities are kept only when somebody will read them: backward, or the head-mean weights
+        keep = need_weights or any(ctx.needs_input_grad[:3])
+        pt = _empty(v, B, H, SP, SP) if keep else None
         drop = (0.0, 0, 0, None)
         if drop_p > 0.0:  # dropout on the probabilities (nn.MultiheadAttention(dropout=p) in train mode)
             drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP, v.device)
-        L.call("stcat_mha_self_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), pt.data_ptr(),
+        L.call("stcat_mha_self_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), L._ptr(pt),
                B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, *drop, L.stream_of(v))
         wts = None
         if need_weights:
             wts = _empty(v, B, S, S)
             L.call("stcat_attn_weights_mean", pt.data_ptr(), wts.data_ptr(), B, H, S, *drop, L.stream_of(v))
         ctx.drop = drop
-        ctx.save_for_backward(q, k, v, o, pt)
+        if keep:
+            ctx.save_for_backward(q, k, v, o, pt)
         ctx.scale = scale
         ctx.packed_qk = packed_qk
         ctx.need_weights = need_weights

@@ -239,6 +239,12 @@ def _mha_case(dev, B, S, H, need_w, packed, masked):
 
 @both
 def _mha_self(dev, big):
+    # inference path: no probability stash (pt = NULL) — same output as the training-path forward
+    qk, v = rnd(2, 37, 128, seed=1).to(dev), rnd(2, 37, 64, seed=2).to(dev)
+    with torch.no_grad():
+        o_inf, _ = ops.mha_self_packed(qk, v, None, 32 ** -0.5)
+    o_trn, _ = ops.mha_self_packed(qk.clone().requires_grad_(True), v, None, 32 ** -0.5)
+    assert torch.equal(o_inf.cpu(), o_trn.detach().cpu())
     _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)
     _mha_case(dev, 1, 8, 2, need_w=True, packed=True, masked=False)
     _mha_case(dev, 1, 65, 1, need_w=True, packed=False, masked=True)

@@ -26,4 +26,7 @@ def fb():
     o = fwd(); o.backward(go); qk.grad = None; v.grad = None
 t_fb = timeit(fb)
 fl = 2.0 * 2 * B * H * S * S * 32
+with torch.no_grad():
+    t_inf = timeit(lambda: ops.mha_self_packed(qk.detach(), v.detach(), kpm, 32 ** -0.5)[0])
+print(f"S={S}: inference fwd (no probability stash) {t_inf*1e3:.1f} us = {fl/t_inf/1e9:.1f} TF")
 print(f"S={S}: fwd {t_f*1e3:.1f} us = {fl/t_f/1e9:.1f} TF (QK^T+PV, unpadded flops); fwd+bwd {t_fb*1e3:.1f} us = {3*fl/t_fb/1e9:.1f} TF")
