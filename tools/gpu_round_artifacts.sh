@@ -11,6 +11,5 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$TAG -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-exact --no-profile > /dev/null 2>&1
 cd $R
 cp /tmp/prof_$TAG/*kernel_stats.csv gpurun_out/$TAG/bench_kernel_stats.csv 2>/dev/null
-python tools/trace_gaps.py /tmp/prof_$TAG > gpurun_out/$TAG/gpu_idle.json 2>&1; cat gpurun_out/$TAG/gpu_idle.json
 python tools/pmc_traffic.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG > gpurun_out/$TAG/hbm_traffic.json
 head -c 1500 gpurun_out/$TAG/hbm_traffic.json
