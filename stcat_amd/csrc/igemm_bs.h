@@ -94,8 +94,8 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
 // with 80-byte rows that puts them on disjoint halves of the 32 write banks (adjacent rows overlap by 4).
 #define STCAT_BS_STORE_R(DST, ROWS, REGS)                                                                \
   STCAT_UNROLL                                                                                           \
-  for (int j = 0; j < (ROWS) / 32; ++j)                                                                  \
-    stcat_bs_split_store<NS>(&(DST)[(trow + 32 * j) * LDK + (t & 7) * 4]    , (ROWS) * LDK, (REGS)[j].x, \
+  for (int j = 0; j < (ROWS) / RP; ++j)                                                                  \
+    stcat_bs_split_store<NS>(&(DST)[(trow + RP * j) * LDK + (t & 7) * 4]    , (ROWS) * LDK, (REGS)[j].x, \
                              (REGS)[j].y, (REGS)[j].z, (REGS)[j].w);
 
 // ---- O-type staging of a [32(k) x ROWS] tile: block i = t + 256*j -> kgrp = i & 7 (4 k's), rowgrp = i >> 3 (4 rows).
@@ -119,12 +119,12 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
 // STCAT_BUF_OOB (hardware zero-fill).  Recomputed only when the tap changes; the channel offset inside the
 // tap rides in the scalar soffset of the buffer load.
 #define STCAT_BS_GATHER_DECL(ROWS)                                                                       \
-  int a_nb[(ROWS) / 32], a_bh[(ROWS) / 32], a_bw[(ROWS) / 32];                                           \
-  unsigned a_off[(ROWS) / 32];                                                                           \
+  int a_nb[(ROWS) / RP], a_bh[(ROWS) / RP], a_bw[(ROWS) / RP];                                           \
+  unsigned a_off[(ROWS) / RP];                                                                           \
   int cur_tap = -1;                                                                                      \
   STCAT_UNROLL                                                                                           \
-  for (int j = 0; j < (ROWS) / 32; ++j) {                                                                \
-    const int m = m0 + trow + 32 * j;                                                                    \
+  for (int j = 0; j < (ROWS) / RP; ++j) {                                                                \
+    const int m = m0 + trow + RP * j;                                                                    \
     a_off[j] = STCAT_BUF_OOB;                                                                            \
     if (m < p.M) {                                                                                       \
       const int ohw = g.OH * g.OW;                                                                       \
@@ -142,14 +142,14 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
       cur_tap = tap;                                                                                     \
       const int kh = tap / g.KW, kw = tap - kh * g.KW;                                                   \
       STCAT_UNROLL                                                                                       \
-      for (int j = 0; j < (ROWS) / 32; ++j) {                                                            \
+      for (int j = 0; j < (ROWS) / RP; ++j) {                                                            \
         const long pix = a_nb[j] < 0 ? -1 : stcat_gather_pix(g, a_nb[j], a_bh[j], a_bw[j], kh, kw);      \
         a_off[j] = pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (t & 7) * 16;                         \
       }                                                                                                  \
     }                                                                                                    \
     const stcat_buf_t bA_ = stcat_make_buf(p.A, (KT) < nk ? p.a_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
-    for (int j = 0; j < (ROWS) / 32; ++j) ra[SET][j] = stcat_buf_ld4(bA_, a_off[j], (unsigned)c0 * 4);   \
+    for (int j = 0; j < (ROWS) / RP; ++j) ra[SET][j] = stcat_buf_ld4(bA_, a_off[j], (unsigned)c0 * 4);   \
   }
 
 // Software pipeline shared by the three kernels: LDS double buffer + two register sets, so the global loads of
@@ -221,7 +221,8 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
   __syncthreads();
 
 #define STCAT_BS_PROLOGUE                                                                                \
-  constexpr int BK = 32, LDK = STCAT_BS_LDK, TM = BM / 64, TN = BN / 64;                                 \
+  constexpr int NTHR = NWV * 64, RP = NTHR / 8;   /* threads; rows staged per pass of the R-type path */  \
+  constexpr int BK = 32, LDK = STCAT_BS_LDK, TM = BM / (NWV * 16), TN = BN / 64;  /* waves: (NWV/2) x 2 */ \
   constexpr int A_ELEMS = NS * BM * LDK, B_ELEMS = NS * BN * LDK, LDC = BN + 4;                          \
   constexpr int SMEM_BYTES = (2 * (A_ELEMS + B_ELEMS) * 2 > BM * LDC * 4) ? 2 * (A_ELEMS + B_ELEMS) * 2 : BM * LDC * 4; \
   __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];                                     \
@@ -241,15 +242,18 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NS>
-__global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
+// NWV = 4: 2x2 waves, two workgroups per CU.  NWV = 8 (256x128 tile): 4x2 waves, ONE workgroup per CU — a K step
+// then carries twice the MFMA work per barrier while only 1.5x the operand bytes (tools/bench_quant.py: a second
+// co-resident 4-wave workgroup adds no throughput, so the CU is better spent on one bigger tile).
+template <int BM, int BN, int NS, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   STCAT_BS_PROLOGUE
   STCAT_BS_GATHER_DECL(BM)
   STCAT_BS_ACC_INIT
-  unsigned b_off[BN / 32];
+  unsigned b_off[BN / RP];
   STCAT_UNROLL
-  for (int j = 0; j < BN / 32; ++j) b_off[j] = (unsigned)((n0 + trow + 32 * j) * p.ldb + (t & 7) * 4) * 4;
-  float4 ra[2][BM / 32], rb[2][BN / 32];
+  for (int j = 0; j < BN / RP; ++j) b_off[j] = (unsigned)((n0 + trow + RP * j) * p.ldb + (t & 7) * 4) * 4;
+  float4 ra[2][BM / RP], rb[2][BN / RP];
   const int nk = p.K / BK;
 #define STCAT_BSF_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
     const unsigned soffb = (unsigned)tapb * p.b_tap_stride + (unsigned)c0b * 4;                          \
     const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < nk ? p.b_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
-    for (int j = 0; j < BN / 32; ++j) rb[SET][j] = stcat_buf_ld4(bB_, b_off[j], soffb);                  \
+    for (int j = 0; j < BN / RP; ++j) rb[SET][j] = stcat_buf_ld4(bB_, b_off[j], soffb);                  \
   }
 #define STCAT_BSF_STORE(SET, BUF) \
   STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
@@ -268,8 +272,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
   STCAT_BS_ACC_TO_LDS
   constexpr int F4 = BN / 4;
   STCAT_UNROLL
-  for (int j = 0; j < BM * F4 / 256; ++j) {
-    const int i = t + 256 * j, row = i / F4, c4 = i - row * F4;
+  for (int j = 0; j < BM * F4 / NTHR; ++j) {
+    const int i = t + NTHR * j, row = i / F4, c4 = i - row * F4;
     const int m = m0 + row, n = n0 + c4 * 4;
     if (m < p.M) {
       float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
@@ -307,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_fwd_kernel(IgemmParams p) {
 // ---------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS>
 __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
+  constexpr int NWV = 4;
   STCAT_BS_PROLOGUE
   constexpr int JB = (BN * 2 + 255) / 256;
   STCAT_BS_GATHER_DECL(BM)
@@ -341,8 +346,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
   STCAT_BS_ACC_TO_LDS
   constexpr int F4 = BN / 4;
   STCAT_UNROLL
-  for (int j = 0; j < BM * F4 / 256; ++j) {
-    const int i = t + 256 * j, row = i / F4, c4 = i - row * F4;
+  for (int j = 0; j < BM * F4 / NTHR; ++j) {
+    const int i = t + NTHR * j, row = i / F4, c4 = i - row * F4;
     const int m = m0 + row, n = n0 + c4 * 4;
     if (m < p.M) {
       float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
@@ -371,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
 // ---------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS>
 __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
+  constexpr int NWV = 4;
   STCAT_BS_PROLOGUE
   constexpr int JA = (BM * 2 + 255) / 256, JB = (BN * 2 + 255) / 256;
   const int tap = n0 / g.C, ci0 = n0 - tap * g.C;

@@ -100,6 +100,20 @@ inline bool bs_ok(const IgemmParams& p) {
 int launch_fwd(const IgemmParams& p, hipStream_t st) {
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
+  // Less than one round of 128x128 tiles on the 512 resident slots and a long reduction (layer4's convs): one
+  // 8-wave 256x128 workgroup per CU is 20-25 % faster there (tools/bench_gemm.py --tile 256x128); elsewhere the
+  // two-workgroup 128x128 form wins.
+  if (!g_force_bm && p.N % 128 == 0 && p.K >= 1024 && (long)cdiv(p.M, 128) * (p.N / 128) < 512 &&
+      (long)cdiv(p.M, 256) * (p.N / 128) >= 160) {  // ... and still a workgroup for most of the 256 CUs
+    BM = 256;
+    BN = 128;
+  }
+  if (BM == 256 && !(bs_ok(p) && g_mma_mode == 2)) pick_tile(p.M, p.N, BM, BN);  // 8-wave tile: bf16x3 only (LDS)
+  if (BM == 256 && !(bs_ok(p) && g_mma_mode == 2)) BM = 128;                       // (forced by the debug hook)
+  if (BM == 256) {  // 8-wave 256x128 tile, one workgroup per CU
+    STCAT_LAUNCH((igemm_bs_fwd_kernel<256, 128, 2, 8>), dim3(cdiv(p.M, 256) * (p.N / 128)), dim3(512), 0, st, p);
+    return launch_status();
+  }
   const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
   if (bs_ok(p)) {
     if (g_mma_mode == 3) { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 3) } else { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 2) }
@@ -112,6 +126,7 @@ int launch_fwd(const IgemmParams& p, hipStream_t st) {
 int launch_dgrad(const IgemmParams& p, hipStream_t st) {
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
+  if (BM == 256) BM = 128;
   const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
   if (bs_ok(p)) {
     if (g_mma_mode == 3) { STCAT_TILE_SWITCH_BS(igemm_bs_dgrad_kernel, grid, 3) } else { STCAT_TILE_SWITCH_BS(igemm_bs_dgrad_kernel, grid, 2) }
@@ -177,7 +192,8 @@ int stcat_set_mma_mode(int mode) {
 int stcat_get_mma_mode(void) { return g_mma_mode; }
 
 int stcat_debug_force_tile(int bm, int bn) {
-  const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64);
+  const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64) ||
+                  (bm == 256 && bn == 128);
   if (!ok) return fail("debug_force_tile: unsupported tile %dx%d", bm, bn);
   g_force_bm = bm;
   g_force_bn = bn;

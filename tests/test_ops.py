@@ -514,6 +514,14 @@ def _gemm_bf16x3(dev, big):
     # products carry ~2^-16 relative error (two bf16 pieces per operand)
     with mma_mode("bf16x3", 1e-3):
         _gemm_family(dev, big)
+        # the 8-wave 256x128 tile (one workgroup per CU): ragged M, 3x3 with padding, strided 1x1, residual + ReLU,
+        # and the data gradient that runs through the same kernel on pre-transposed weights
+        _linear_case(dev, 300, 128, 64, relu=True, res=True, tile=(256, 128))
+        _conv_case(dev, 2, 13, 11, 64, 128, 3, 1, 1, relu=True, res=True, tile=(256, 128))
+        _conv_case(dev, 1, 18, 17, 64, 256, 1, 2, 0, relu=False, res=False, tile=(256, 128))
+        if big:
+            _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, tile=(256, 128))
+            _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True, tile=(256, 128))
 
 
 @both
