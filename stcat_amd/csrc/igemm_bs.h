@@ -98,13 +98,13 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
     stcat_bs_split_store<NS>(&(DST)[(trow + RP * j) * LDK + (t & 7) * 4]    , (ROWS) * LDK, (REGS)[j].x, \
                              (REGS)[j].y, (REGS)[j].z, (REGS)[j].w);
 
-// ---- O-type staging of a [32(k) x ROWS] tile: block i = t + 256*j -> kgrp = i & 7 (4 k's), rowgrp = i >> 3 (4 rows).
+// ---- O-type staging of a [32(k) x ROWS] tile: block i = t + NTHR*j -> kgrp = i & 7 (4 k's), rowgrp = i >> 3 (4 rows).
 // A 16-lane group then writes 8 x 8 B = one contiguous 64-B row segment for each of two row groups 320 B apart
 // (conflict-free), and its global reads are 8 rows x 128 contiguous bytes (full lines).
 #define STCAT_BS_STORE_O(DST, ROWS, REGS)                                                                \
   STCAT_UNROLL                                                                                           \
-  for (int j = 0; j < ((ROWS) * 2 + 255) / 256; ++j) {                                                   \
-    const int i = t + 256 * j;                                                                           \
+  for (int j = 0; j < ((ROWS) * 2 + NTHR - 1) / NTHR; ++j) {                                             \
+    const int i = t + NTHR * j;                                                                          \
     if (i < (ROWS) * 2) {                                                                                \
       const int kgrp = i & 7, rowgrp = i >> 3;                                      \
       __bf16* d = &(DST)[(rowgrp * 4) * LDK + kgrp * 4];                                                 \
@@ -374,11 +374,10 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
 // ---------------------------------------------------------------------------------------------------
 // wgrad: A[k=pixel][row=co] = dY (O), B[k=pixel][col=(tap,ci)] = gathered X (O); split-K over grid.z, atomics
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NS>
-__global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
-  constexpr int NWV = 4;
+template <int BM, int BN, int NS, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
   STCAT_BS_PROLOGUE
-  constexpr int JA = (BM * 2 + 255) / 256, JB = (BN * 2 + 255) / 256;
+  constexpr int JA = (BM * 2 + NTHR - 1) / NTHR, JB = (BN * 2 + NTHR - 1) / NTHR;
   const int tap = n0 / g.C, ci0 = n0 - tap * g.C;
   const int kh = tap / g.KW, kw = tap - kh * g.KW;
   const int red0 = blockIdx.z * p.k_chunk;
@@ -390,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
   unsigned a_off[JA][4];
   STCAT_UNROLL
   for (int j = 0; j < JA; ++j) {
-    const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;
+    const int i = t + NTHR * j, kgrp = i & 7, rowgrp = i >> 3;
     STCAT_UNROLL
     for (int e = 0; e < 4; ++e)
       a_off[j][e] = i < BM * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + m0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
@@ -409,14 +408,14 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
     const unsigned soff = (unsigned)mbase * (unsigned)p.ldb * 4u;                                        \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < JA; ++j) {                                                                       \
-      const int kgrp = (t + 256 * j) & 7;                                                                \
+      const int kgrp = (t + NTHR * j) & 7;                                                                \
       STCAT_UNROLL                                                                                       \
       for (int e = 0; e < 4; ++e)                                                                        \
         ra[SET][j][e] = stcat_buf_ld4(bufA, mbase + kgrp * 4 + e < red1 ? a_off[j][e] : STCAT_BUF_OOB, soff); \
     }                                                                                                    \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < JB; ++j) {                                                                       \
-      const int i = t + 256 * j, kgrp = i & 7, rowgrp = i >> 3;                                          \
+      const int i = t + NTHR * j, kgrp = i & 7, rowgrp = i >> 3;                                          \
       const int mfirst = mbase + kgrp * 4;                                                               \
       int nb = stcat_fastdiv(mfirst, g.mg_ohw, g.sh_ohw);                                                \
       const int rem = mfirst - nb * ohw;                                                                 \
@@ -457,7 +456,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
   if (do_rs) {
     STCAT_UNROLL
     for (int j = 0; j < JA; ++j) {
-      const int i = t + 256 * j;
+      const int i = t + NTHR * j;
       if (i < BM * 2) {  // wave-uniform (BM*2 is a multiple of 64)
         float4 v = rs[j];
         STCAT_UNROLL

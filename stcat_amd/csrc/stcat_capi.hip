@@ -138,12 +138,18 @@ int launch_dgrad(const IgemmParams& p, hipStream_t st) {
 
 // rows = output rows (Cout / N_lin), cols = output columns (KH*KW*Cin / K_lin), red = reduction length (pixels)
 int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
+  const bool bs = g_mma_mode != 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu;
+  // 8-wave 256x128 tile, ONE workgroup per CU and at most one round of them: the most efficient configuration
+  // measured for long reductions (tools/bench_quant.py); needs Cout % 256 == 0 (layer3/4, the FFN)
+  const bool big8 = bs && g_mma_mode == 2 && (rows % 256 == 0) && (p.g.C % 128 == 0) &&
+                    (g_force_bm == 256 || (!g_force_bm && red >= 4096));
   const bool big = (rows % 128 == 0) && (p.g.C % 128 == 0) && g_force_bm != 64;
-  const int BM = big ? 128 : 64, BN = big ? 128 : 64;
+  const int BM = big8 ? 256 : (big ? 128 : 64), BN = big8 ? 128 : (big ? 128 : 64);
   const int tiles = (rows / BM) * (cols / BN);
-  // split the reduction so that the grid is at most 1024 workgroups = two full rounds of the 512 resident slots
-  // (2 per CU): rounding UP here put 1044 blocks on the layer3 3x3 conv — a third, almost empty round
-  int nsplit = 1024 / tiles;
+  // split the reduction so that the grid is at most two full rounds of the resident slots (512 four-wave or
+  // 256 eight-wave workgroups): rounding UP here put 1044 blocks on the layer3 3x3 conv — a third, almost empty round
+  const int slots = big8 ? 256 : 1024;
+  int nsplit = slots / tiles;
   const int max_split = cdiv(red, 256);  // at least 8 K-tiles per workgroup: shorter loops are all prologue + atomics
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -155,7 +161,9 @@ int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
   p.K = red;
   p.k_chunk = chunk;
   const dim3 grid(tiles, 1, nsplit);
-  if (g_mma_mode != 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu) {
+  if (big8) {
+    STCAT_LAUNCH((igemm_bs_wgrad_kernel<256, 128, 2, 8>), grid, dim3(512), 0, st, p);
+  } else if (bs) {
     if (big) {
       if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_wgrad_kernel<128, 128, 3>), grid, dim3(256), 0, st, p); }
       else { STCAT_LAUNCH((igemm_bs_wgrad_kernel<128, 128, 2>), grid, dim3(256), 0, st, p); }

@@ -519,6 +519,10 @@ def _gemm_bf16x3(dev, big):
         _linear_case(dev, 300, 128, 64, relu=True, res=True, tile=(256, 128))
         _conv_case(dev, 2, 13, 11, 64, 128, 3, 1, 1, relu=True, res=True, tile=(256, 128))
         _conv_case(dev, 1, 18, 17, 64, 256, 1, 2, 0, relu=False, res=False, tile=(256, 128))
+        # ... and the 8-wave weight-gradient tile (Cout % 256 == 0, Cin % 128 == 0), 1x1 and padded 3x3, + bias sums
+        _conv_case(dev, 2, 6, 7, 128, 256, 1, 1, 0, relu=True, res=False, tile=(256, 128))
+        _conv_case(dev, 1, 5, 6, 128, 256, 3, 1, 1, relu=False, res=True, tile=(256, 128))
+        _linear_case(dev, 100, 256, 128, relu=False, res=False, tile=(256, 128))
         if big:
             _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, tile=(256, 128))
             _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True, tile=(256, 128))
