@@ -8,7 +8,8 @@
 // 3 (6) MFMAs of 32 cycles replace 8 fp32 MFMAs of 64 cycles per 16 reduction terms: 5.3x (2.7x) less matrix
 // pipe time at fp32-input / fp32-output semantics.  Activations and weights stay fp32 in HBM.
 //
-// Tiling: 256 threads = 2x2 waves, BMxBN block tile, K step 32.  LDS holds one plane per split piece,
+// Tiling: 256 threads = 2x2 waves (two workgroups per CU) or 512 threads = 4x2 waves on a 256x128 tile (ONE workgroup
+// per CU; forward / weight gradient), BMxBN block tile, K step 32.  LDS holds one plane per split piece,
 // rows of 32 bf16 padded to 40 (80 B): an MFMA fragment is one 16-byte ds_read_b128 per lane and the 80-byte
 // row stride is conflict-free for its 16-lane groups.  Two staging paths:
 //   R : operand rows are contiguous along the reduction (NHWC pixels x channels, weights [N][K]) —
