@@ -33,6 +33,9 @@ int stcat_set_mma_mode(int mode);
 int stcat_get_mma_mode(void);
 /* tuning/test hook: force the implicit-GEMM block tile (128x128, 128x64, 64x64; 0,0 = heuristic) */
 int stcat_debug_force_tile(int bm, int bn);
+/* stream-K scheduling of the split-bf16 forward GEMM (opt-in experiment): 1 whenever legal,
+ * 0 / -1 off (default) */
+int stcat_debug_streamk(int mode);
 
 /* ---- backbone: torchvision ResNet-101 + FrozenBatchNorm2d (models/vision_model/backbone.py:16-66,
  *      93-121; torch conv2d/max_pool2d underneath) ------------------------------------------------ */

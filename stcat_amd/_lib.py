@@ -51,6 +51,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_optim_table_entry_bytes": "",
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_debug_force_tile": "ii",
+    "stcat_debug_streamk": "i",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
 }

@@ -51,6 +51,7 @@ struct IgemmParams {
   float* C2;           // dgrad only: optional second output C2 = C * c2scale[n] (dz and dz*scale of a block boundary)
   const float* c2scale;
   float* rowsum;       // wgrad only: optional rowsum[m] += sum_k A[k][m] (the bias gradient of a Linear)
+  float* sk_ws;        // stream-K forward only: partial-tile workspace, 2 slots of BM*BN floats per worker
   int M, N, K;
   int ldb, ldc, ldr;
   int c_group, c_group_stride;  // output row m -> (m / c_group) * c_group_stride + (m % c_group) * ldc

@@ -148,7 +148,7 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
         a_off[j] = pix < 0 ? STCAT_BUF_OOB : (unsigned)(pix * 4) + (t & 7) * 16;                         \
       }                                                                                                  \
     }                                                                                                    \
-    const stcat_buf_t bA_ = stcat_make_buf(p.A, (KT) < nk ? p.a_bytes : 0u);                             \
+    const stcat_buf_t bA_ = stcat_make_buf(p.A, (KT) < kend ? p.a_bytes : 0u);                             \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < (ROWS) / RP; ++j) ra[SET][j] = stcat_buf_ld4(bA_, a_off[j], (unsigned)c0 * 4);   \
   }
@@ -187,22 +187,25 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
     STCAT_SCHED_GROUP(0x020, 1);                                                                         \
   }
 #endif
-#define STCAT_BS_PIPELINE(LOAD, STORE)                                                                   \
-  LOAD(0, 0)                                                                                             \
-  LOAD(1, 1)                                                                                             \
+#define STCAT_BS_PIPELINE(LOAD, STORE) STCAT_BS_PIPELINE_RANGE(LOAD, STORE, 0, nk)
+// K-tiles [KB, KE) of the reduction (stream-K segments start and stop inside a tile's reduction); LOAD must treat
+// tiles >= `kend` as past the end
+#define STCAT_BS_PIPELINE_RANGE(LOAD, STORE, KB, KE)                                                     \
+  LOAD((KB), 0)                                                                                          \
+  LOAD((KB) + 1, 1)                                                                                      \
   STORE(0, 0)                                                                                            \
   __syncthreads();                                                                                       \
-  for (int kt = 0; kt < nk; kt += 2) {                                                                   \
+  for (int kt = (KB); kt < (KE); kt += 2) {                                                              \
     STCAT_EXP_LOAD(LOAD(kt + 2, 0))                                                                      \
     STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[0], Bs[0]))                                                    \
     STCAT_BS_INTERLEAVE                                                                                  \
-    if (kt + 1 < nk) { STCAT_EXP_STORE(STORE(1, 1)) }                                                    \
+    if (kt + 1 < (KE)) { STCAT_EXP_STORE(STORE(1, 1)) }                                                  \
     __syncthreads();                                                                                     \
-    if (kt + 1 >= nk) break;                                                                             \
+    if (kt + 1 >= (KE)) break;                                                                           \
     STCAT_EXP_LOAD(LOAD(kt + 3, 1))                                                                      \
     STCAT_EXP_COMPUTE(STCAT_BS_COMPUTE(As[1], Bs[1]))                                                    \
     STCAT_BS_INTERLEAVE                                                                                  \
-    if (kt + 2 < nk) { STCAT_EXP_STORE(STORE(0, 0)) }                                                    \
+    if (kt + 2 < (KE)) { STCAT_EXP_STORE(STORE(0, 0)) }                                                  \
     __syncthreads();                                                                                     \
   }
 
@@ -234,11 +237,46 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
   const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;                              \
   const int trow = ((t >> 3) & ~7) | (((t >> 3) & 1) << 2) | ((t >> 4) & 3);                             \
   const int num_n = p.N / BN;                                                                            \
-  const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);                                                  \
-  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;                                                \
   const IgemmGeom g = p.g;                                                                               \
   const stcat_buf_t bufA = stcat_make_buf(p.A, p.a_bytes);                                               \
-  const stcat_buf_t bufB = stcat_make_buf(p.B, p.b_bytes);
+  const stcat_buf_t bufB = stcat_make_buf(p.B, p.b_bytes);                                               \
+  STCAT_BS_TILE_OF_BLOCK
+// which output tile a workgroup owns: one per block (XCD-aware remap) — the stream-K kernel overrides this
+#define STCAT_BS_TILE_OF_BLOCK_DEFAULT                                                                   \
+  const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);                                                  \
+  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;
+#define STCAT_BS_TILE_OF_BLOCK STCAT_BS_TILE_OF_BLOCK_DEFAULT
+
+// forward epilogue of one float4 of output row m, columns n..n+3 (also the data gradient through this kernel on
+// pre-transposed weights: mask / mscale = fused ReLU+BN backward of the layer below, C2 = second scaled output)
+#define STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)                                                               \
+  {                                                                                                      \
+    if (p.scale) {                                                                                       \
+      const float4 sc = stcat_ld4(p.scale + (n));                                                        \
+      v4.x *= sc.x; v4.y *= sc.y; v4.z *= sc.z; v4.w *= sc.w;                                            \
+    }                                                                                                    \
+    if (p.bias) {                                                                                        \
+      const float4 bi = stcat_ld4(p.bias + (n));                                                         \
+      v4.x += bi.x; v4.y += bi.y; v4.z += bi.z; v4.w += bi.w;                                            \
+    }                                                                                                    \
+    if (p.res) {                                                                                         \
+      const float4 rr = stcat_ld4(p.res + (long)(m) * p.ldr + (n));                                      \
+      v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;                                            \
+    }                                                                                                    \
+    if (p.relu) { v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f); } \
+    if (p.mask) {                                                                                        \
+      const float4 mk = stcat_ld4(p.mask + (long)(m) * p.ldc + (n));                                     \
+      float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);                                                       \
+      if (p.mscale) ms = stcat_ld4(p.mscale + (n));                                                      \
+      v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;                      \
+      v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;                      \
+    }                                                                                                    \
+    stcat_st4(p.C + (long)(m) * p.ldc + (n), v4);                                                        \
+    if (p.C2) {                                                                                          \
+      const float4 s2 = stcat_ld4(p.c2scale + (n));                                                      \
+      stcat_st4(p.C2 + (long)(m) * p.ldc + (n), make_float4(v4.x * s2.x, v4.y * s2.y, v4.z * s2.z, v4.w * s2.w)); \
+    }                                                                                                    \
+  }
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -255,13 +293,13 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
   STCAT_UNROLL
   for (int j = 0; j < BN / RP; ++j) b_off[j] = (unsigned)((n0 + trow + RP * j) * p.ldb + (t & 7) * 4) * 4;
   float4 ra[2][BM / RP], rb[2][BN / RP];
-  const int nk = p.K / BK;
+  const int nk = p.K / BK, kend = nk;
 #define STCAT_BSF_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
   {                                                                                                      \
     const int r0b = (KT) * BK, tapb = r0b / g.C, c0b = r0b - tapb * g.C;                                 \
     const unsigned soffb = (unsigned)tapb * p.b_tap_stride + (unsigned)c0b * 4;                          \
-    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < nk ? p.b_bytes : 0u);                             \
+    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < kend ? p.b_bytes : 0u);                           \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < BN / RP; ++j) rb[SET][j] = stcat_buf_ld4(bB_, b_off[j], soffb);                  \
   }
@@ -278,31 +316,105 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
     const int m = m0 + row, n = n0 + c4 * 4;
     if (m < p.M) {
       float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
-      if (p.scale) {
-        const float4 sc = stcat_ld4(p.scale + n);
-        v4.x *= sc.x; v4.y *= sc.y; v4.z *= sc.z; v4.w *= sc.w;
+      STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stream-K forward (bf16x3, 8-wave 256x128 tiles): ONE workgroup per CU, each owning an equal share of the
+// tiles x K-steps space.  A layer3 launch has 392 such tiles for 256 CUs: tile-per-workgroup scheduling runs two
+// rounds (the second 53 % full); here every CU gets 110 K-steps: at most one tile tail, whole tiles, one tile head.
+// Whole tiles take the normal epilogue.  The two partial pieces of a worker go to workspace slots (2w: tail piece
+// [kb, nk) of its first tile, 2w+1: head piece [0, ke) of its last tile) as raw fp32 tiles, and a second small
+// kernel adds the two halves of every split tile (tail of worker w + head of worker w-1) and applies the epilogue.
+// The kernel boundary is the only synchronisation: no flags, no spinning, no cross-XCD visibility games.
+// Requires tiles >= workers (so a tile is split between at most two workers).
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS, int NWV>
+__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_sk_kernel(IgemmParams p) {
+#undef STCAT_BS_TILE_OF_BLOCK
+#define STCAT_BS_TILE_OF_BLOCK
+  STCAT_BS_PROLOGUE
+#undef STCAT_BS_TILE_OF_BLOCK
+#define STCAT_BS_TILE_OF_BLOCK STCAT_BS_TILE_OF_BLOCK_DEFAULT
+  const int nk = p.K / BK;
+  const int n_tiles = ((p.M + BM - 1) / BM) * num_n;
+  const long S = (long)n_tiles * nk;
+  const int w = blockIdx.x, G = gridDim.x;
+  long s = (long)w * S / G;
+  const long s1 = (long)(w + 1) * S / G;
+  constexpr int F4 = BN / 4;
+  while (s < s1) {
+    const int tile = (int)(s / nk), kb = (int)(s - (long)tile * nk);
+    const int ke = (s1 - s) < (long)(nk - kb) ? kb + (int)(s1 - s) : nk;
+    const int kend = ke;
+    const int m0 = (tile / num_n) * BM, n0 = (tile % num_n) * BN;
+    STCAT_BS_GATHER_DECL(BM)
+    STCAT_BS_ACC_INIT
+    unsigned b_off[BN / RP];
+    STCAT_UNROLL
+    for (int j = 0; j < BN / RP; ++j) b_off[j] = (unsigned)((n0 + trow + RP * j) * p.ldb + (t & 7) * 4) * 4;
+    float4 ra[2][BM / RP], rb[2][BN / RP];
+#define STCAT_BSF_LOAD(KT, SET)                                                                          \
+  STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
+  {                                                                                                      \
+    const int r0b = (KT) * BK, tapb = r0b / g.C, c0b = r0b - tapb * g.C;                                 \
+    const unsigned soffb = (unsigned)tapb * p.b_tap_stride + (unsigned)c0b * 4;                          \
+    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < kend ? p.b_bytes : 0u);                           \
+    STCAT_UNROLL                                                                                         \
+    for (int j = 0; j < BN / RP; ++j) rb[SET][j] = stcat_buf_ld4(bB_, b_off[j], soffb);                  \
+  }
+#define STCAT_BSF_STORE(SET, BUF) \
+  STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
+    STCAT_BS_PIPELINE_RANGE(STCAT_BSF_LOAD, STCAT_BSF_STORE, kb, ke)
+#undef STCAT_BSF_LOAD
+#undef STCAT_BSF_STORE
+    STCAT_BS_ACC_TO_LDS
+    if (kb == 0 && ke == nk) {
+      STCAT_UNROLL
+      for (int j = 0; j < BM * F4 / NTHR; ++j) {
+        const int i = t + NTHR * j, row = i / F4, c4 = i - row * F4;
+        const int m = m0 + row, n = n0 + c4 * 4;
+        if (m < p.M) {
+          float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
+          STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)
+        }
       }
-      if (p.bias) {
-        const float4 bi = stcat_ld4(p.bias + n);
-        v4.x += bi.x; v4.y += bi.y; v4.z += bi.z; v4.w += bi.w;
+    } else {  // partial sum of a split tile -> this worker's workspace slot (raw fp32 tile, row-major BM x BN)
+      float* slot = p.sk_ws + ((long)w * 2 + (kb == 0 ? 1 : 0)) * (BM * BN);
+      STCAT_UNROLL
+      for (int j = 0; j < BM * F4 / NTHR; ++j) {
+        const int i = t + NTHR * j, row = i / F4, c4 = i - row * F4;
+        stcat_st4(slot + row * BN + c4 * 4, stcat_ld4(&Cs[row * LDC + c4 * 4]));
       }
-      if (p.res) {
-        const float4 rr = stcat_ld4(p.res + (long)m * p.ldr + n);
-        v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;
-      }
-      if (p.relu) { v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f); }
-      if (p.mask) {  // dgrad through this kernel (pre-transposed weights): fused ReLU+BN backward of the layer below
-        const float4 mk = stcat_ld4(p.mask + (long)m * p.ldc + n);
-        float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.mscale) ms = stcat_ld4(p.mscale + n);
-        v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;
-        v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;
-      }
-      stcat_st4(p.C + (long)m * p.ldc + n, v4);
-      if (p.C2) {
-        const float4 s2 = stcat_ld4(p.c2scale + n);
-        stcat_st4(p.C2 + (long)m * p.ldc + n, make_float4(v4.x * s2.x, v4.y * s2.y, v4.z * s2.z, v4.w * s2.w));
-      }
+    }
+    __syncthreads();  // the fp32 tile aliases the operand stages of the next segment
+    s += ke - kb;
+  }
+}
+
+// second kernel of the stream-K forward: block w finishes the tile that worker w entered in the middle
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_bs_fwd_sk_fixup_kernel(IgemmParams p, int n_workers) {
+  const int t = threadIdx.x, w = blockIdx.x;
+  const int num_n = p.N / BN, nk = p.K / 32;
+  const int n_tiles = ((p.M + BM - 1) / BM) * num_n;
+  const long S = (long)n_tiles * nk;
+  const long s0 = (long)w * S / n_workers;
+  const int tile = (int)(s0 / nk), kb = (int)(s0 - (long)tile * nk);
+  if (kb == 0) return;  // this worker started on a tile boundary: nothing was split here
+  const int m0 = (tile / num_n) * BM, n0 = (tile % num_n) * BN;
+  const float* tail = p.sk_ws + ((long)w * 2) * (BM * BN);           // [kb, nk) by worker w
+  const float* head = p.sk_ws + ((long)(w - 1) * 2 + 1) * (BM * BN); // [0, kb) by worker w-1
+  constexpr int F4 = BN / 4;
+  for (int i = t; i < BM * F4; i += 256) {
+    const int row = i / F4, c4 = i - row * F4;
+    const int m = m0 + row, n = n0 + c4 * 4;
+    if (m < p.M) {
+      const float4 a = stcat_ld4(tail + row * BN + c4 * 4), b = stcat_ld4(head + row * BN + c4 * 4);
+      float4 v4 = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+      STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)
     }
   }
 }
@@ -326,13 +438,13 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
       b_off[j][e] = i < BN * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + n0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
   }
   float4 ra[2][BM / 32], rb[2][JB][4];
-  const int nk = p.K / BK;
+  const int nk = p.K / BK, kend = nk;
 #define STCAT_BSD_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
   {                                                                                                      \
     const int r0 = (KT) * BK, tap = r0 / g.C, co0 = r0 - tap * g.C;                                      \
     const unsigned soff = (unsigned)(co0 * p.ldb + tap * p.N) * 4;                                       \
-    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < nk ? p.b_bytes : 0u);                             \
+    const stcat_buf_t bB_ = stcat_make_buf(p.B, (KT) < kend ? p.b_bytes : 0u);                           \
     STCAT_UNROLL                                                                                         \
     for (int j = 0; j < JB; ++j) {                                                                       \
       STCAT_UNROLL                                                                                       \

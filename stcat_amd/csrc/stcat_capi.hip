@@ -97,7 +97,74 @@ inline bool bs_ok(const IgemmParams& p) {
   return g_mma_mode != 0 && p.K % 32 == 0 && p.g.C % 32 == 0 && p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu;
 }
 
+// ---- stream-K forward (igemm_bs.h): one 8-wave workgroup per CU, equal shares of tiles x K-steps ----------------
+int g_streamk = 0;  // 1: stream-K whenever legal, otherwise off   (stcat_debug_streamk)
+#ifdef STCAT_EMU
+static int sk_workspace(float** ws, int* workers) {
+  static float* buf = nullptr;
+  *workers = 3;  // a few "CUs": exercises tile tails, whole tiles and tile heads on small shapes
+  if (!buf) buf = (float*)malloc((size_t)*workers * 2 * 256 * 128 * sizeof(float));
+  *ws = buf;
+  return 0;
+}
+#else
+static int sk_workspace(float** ws, int* workers) {
+  static float* buf[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail("stream-K: no current device");
+  if (!buf[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      return fail("stream-K: cannot query the CU count");
+    // two partial 256x128 fp32 tiles per worker (64 MB on 256 CUs), allocated once per device
+    if (hipMalloc((void**)&buf[dev], (size_t)n * 2 * 256 * 128 * sizeof(float)) != hipSuccess)
+      return fail("stream-K: workspace allocation failed");
+    cus[dev] = n;
+  }
+  *ws = buf[dev];
+  *workers = cus[dev];
+  return 0;
+}
+#endif
+
+// Use it when tile-per-workgroup scheduling would leave a badly filled last round and the reduction is long enough
+// to amortise the partial-tile round trip.
+static bool sk_wanted(const IgemmParams& p, int workers) {
+  if (g_streamk < 0 || !(bs_ok(p) && g_mma_mode == 2) || p.N % 128 != 0 || g_force_bm) return false;
+  const long nt = (long)cdiv(p.M, 256) * (p.N / 128);
+  const int nk = p.K / 32;
+  if (nt < workers || nk < 2) return false;  // a tile may be split between at most two workers
+  // Opt-in only (stcat_debug_streamk(1)).  Measured on the C3 shapes (tools/bench_gemm.py): the partial-tile round
+  // trip (64 MB written + read) and the second launch cost 30-40 us; only the layer3 3x3 conv gains in isolation
+  // (392 tiles, 72 K-steps: 250 -> 264 TF), shapes with 32 K-steps or >= 3 rounds lose 10-25 %, and in the full
+  // step the layer3 gain disappears (84.0 vs 83.5 ms).  An in-kernel fix-up (owner adds the neighbour's partial
+  // after a flag) would halve the overhead; it needs cross-XCD release/acquire and is left for a later round.
+  return g_streamk > 0;
+}
+
 int launch_fwd(const IgemmParams& p, hipStream_t st) {
+  {
+    float* ws = nullptr;
+    int workers = 0;
+#ifdef STCAT_EMU
+    const bool probe = g_streamk > 0;
+#else
+    const bool probe = g_streamk > 0 && bs_ok(p) && g_mma_mode == 2 && !g_force_bm && p.N % 128 == 0 &&
+                       (long)cdiv(p.M, 256) * (p.N / 128) >= 128;  // (no workspace allocation for small problems)
+#endif
+    if (probe) {
+      if (int rc = sk_workspace(&ws, &workers)) return rc;
+      if (sk_wanted(p, workers)) {
+        IgemmParams q = p;
+        q.sk_ws = ws;
+        STCAT_LAUNCH((igemm_bs_fwd_sk_kernel<256, 128, 2, 8>), dim3(workers), dim3(512), 0, st, q);
+        if (int rc = launch_status()) return rc;
+        STCAT_LAUNCH((igemm_bs_fwd_sk_fixup_kernel<256, 128>), dim3(workers), dim3(256), 0, st, q, workers);
+        return launch_status();
+      }
+    }
+  }
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
   // Less than one round of 128x128 tiles on the 512 resident slots and a long reduction (layer4's convs): one
@@ -205,6 +272,11 @@ int stcat_debug_force_tile(int bm, int bn) {
   if (!ok) return fail("debug_force_tile: unsupported tile %dx%d", bm, bn);
   g_force_bm = bm;
   g_force_bn = bn;
+  return 0;
+}
+int stcat_debug_streamk(int mode) {
+  if (mode < -1 || mode > 1) return fail("debug_streamk: mode must be -1, 0 or 1");
+  g_streamk = mode;
   return 0;
 }
 const char* stcat_last_error(void) { return g_err; }

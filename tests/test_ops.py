@@ -523,6 +523,18 @@ def _gemm_bf16x3(dev, big):
         _conv_case(dev, 2, 6, 7, 128, 256, 1, 1, 0, relu=True, res=False, tile=(256, 128))
         _conv_case(dev, 1, 5, 6, 128, 256, 3, 1, 1, relu=False, res=True, tile=(256, 128))
         _linear_case(dev, 100, 256, 128, relu=False, res=False, tile=(256, 128))
+        # stream-K scheduling of the forward GEMM (equal shares of tiles x K-steps per workgroup, split tiles
+        # finished by the fix-up kernel): tile tails, whole tiles and tile heads; also the data gradient through it
+        L.call("stcat_debug_streamk", 1)
+        try:
+            _linear_case(dev, 1000, 128, 128, relu=True, res=True)
+            _conv_case(dev, 2, 23, 23, 64, 128, 3, 1, 1, relu=True, res=True)
+            _conv_case(dev, 1, 40, 41, 64, 256, 1, 2, 0, relu=False, res=False)
+            if big:
+                _conv_case(dev, 64, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
+                _conv_case(dev, 37, 28, 28, 1024, 256, 1, 1, 0, relu=True, res=True)
+        finally:
+            L.call("stcat_debug_streamk", 0)
         if big:
             _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, tile=(256, 128))
             _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True, tile=(256, 128))
