@@ -17,6 +17,7 @@ xGMI is point-to-point (7 links per GPU): few large messages beat many small one
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -43,15 +44,24 @@ class GradBucketReducer:
         self.params = [p for _, p in params]
         cap = int(bucket_mb * (1 << 20) // 4)
         self.buckets: List[Dict] = []
+        # Parameters of a module whose forward runs on a forked stream (QueryDecoder's time decoder) get their
+        # gradients on that stream; they go into their own bucket, reduced in finish() — after backward() the
+        # autograd engine has joined every stream with the caller's, so no cross-stream wait is needed inside a hook
+        # (a wait_stream there stalls the side chain behind everything queued on the main stream: measured 5 ms).
+        late = [(n, p) for n, p in params if getattr(p, "_stcat_forked_stream", False)]
         cur, cur_n = [], 0
         for n, p in params:
+            if getattr(p, "_stcat_forked_stream", False):
+                continue
             if cur and cur_n + p.numel() > cap:
-                self.buckets.append({"params": cur, "numel": cur_n})
+                self.buckets.append({"params": cur, "numel": cur_n, "late": False})
                 cur, cur_n = [], 0
             cur.append((n, p))
             cur_n += p.numel()
         if cur:
-            self.buckets.append({"params": cur, "numel": cur_n})
+            self.buckets.append({"params": cur, "numel": cur_n, "late": False})
+        if late:
+            self.buckets.append({"params": late, "numel": sum(p.numel() for _, p in late), "late": True})
         self._owner = {}
         for bi, b in enumerate(self.buckets):
             dev = b["params"][0][1].device
@@ -75,6 +85,7 @@ class GradBucketReducer:
         self._extra_work = None
         self.extra_numel = extra_numel
         self.deferred = False  # True: hooks do nothing, finish() reduces the (static) gradient tensors afterwards
+        self.no_overlap = bool(os.environ.get("STCAT_REDUCER_NO_OVERLAP"))  # diagnostic: all buckets in finish()
 
     # ---- per step -------------------------------------------------------------------------------
     def zero_grad(self):
@@ -120,7 +131,7 @@ class GradBucketReducer:
             return
         b = self.buckets[self._owner[p]]
         b["pending"] -= 1
-        if b["pending"] == 0:
+        if b["pending"] == 0 and not b["late"] and not self.no_overlap:
             self._launch(b)
 
     def finish(self):

@@ -411,6 +411,8 @@ class QueryDecoder(nn.Module):
         self.temp_decoder = TimeDecoder(n_layers, d, nh, ffn, drop)
         self.time_embed = SeqEmbeddingSine(max_len + 1, d)
         _xavier(self)
+        for prm in self.temp_decoder.parameters():
+            prm._stcat_forked_stream = True  # run() puts this module on a second stream: see dist.GradBucketReducer
 
     def run(self, memory, mem_kpm, mem_pos, frames_cls, video_cls):
         """memory/mem_pos [n,S',256] batch-first; returns hs [L,T,256], ref [L,T,4], time_hs [L,T,256], weights [L,1,T,T]."""
@@ -420,9 +422,16 @@ class QueryDecoder(nn.Module):
         pos_query, temp_query = self.template_generator.run(frames_cls, video_cls)          # :97-99
         anchor = ops.sigmoid(pos_query)                                                      # :101
         time_embed = self.time_embed(T)[:, 0, :]                                             # :120
+        # The box decoder and the time decoder are independent chains of ~650 tiny, latency-bound launches each
+        # (6 sequential layers on [T,256] states): the time decoder runs on a second HIP stream so the two chains
+        # overlap on the GPU.  Autograd replays each backward node on its forward stream, so backward overlaps too.
+        fork = ops.fork_stream(memory)
+        with fork:
+            mem_plus_pos = ops.add_const(memory, mem_pos)                                    # memory + pos  :636
+            time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(),
+                                                     time_embed)
         hs, ref = self.decoder.run(memory, mem_kpm, mem_pos, anchor, time_embed)
-        mem_plus_pos = ops.add_const(memory, mem_pos)                                        # memory + pos  :636
-        time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(), time_embed)
+        fork.join(time_hs, weights)
         return hs, ref, time_hs, weights, pos_query
 
     def forward(self, memory_cache, vis_pos=None, text_cls=None):
