@@ -45,3 +45,17 @@ def test_bench_rccl_path_single_rank_and_json_is_last_line():
     last = [l for l in r.stdout.splitlines() if l.strip()][-1]
     d = json.loads(last)                       # raises if anything (e.g. the RCCL banner) follows the line
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["allreduce_bytes"] > 3e8
+
+
+@pytest.mark.gpu
+def test_bench_graph_option_still_runs():
+    """`bench.py --graph` (whole-step hipGraph, opt-in because it measured slower on ROCm 7.2) must keep working:
+    capture with device-resident dropout counters, zero-arena memset inside the graph, gradient exchange outside."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--graph", "--steps", "2", "--warmup", "1", "--config", "C1",
+           "--no-cpu-baseline", "--no-exact", "--no-optim", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["value"] > 0 and d["config"]["launch"] == "one hipGraph per step"
