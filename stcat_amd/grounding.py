@@ -108,10 +108,11 @@ class TransformerEncoderLayer(nn.Module):
         """x, pos: [B,S,256] batch-first; kpm [B,S] bool or None."""
         D = x.shape[-1]
         p = self.dropout_p if self.training else 0.0
-        W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        (Wqk, Wv), (Bqk, Bv) = (ops.split_rows(self.self_attn.in_proj_weight, (2 * D, D)),
+                                ops.split_rows(self.self_attn.in_proj_bias, (2 * D, D)))
         qk_in = ops.add_const(x, pos) if pos_is_const else ops.add(x, pos)      # q = k = src + pos   :234
-        qk = ops.linear(qk_in, W[:2 * D], Bi[:2 * D])                           # packed q|k projection
-        v = ops.linear(x, W[2 * D:], Bi[2 * D:])                                # value = src         :236
+        qk = ops.linear(qk_in, Wqk, Bqk)                                        # packed q|k projection
+        v = ops.linear(x, Wv, Bv)                                               # value = src         :236
         a, _ = ops.mha_self_packed(qk, v, kpm, (D // self.nhead) ** -0.5, drop_p=p)
         z = _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a, x, p)
         x = _ln(self.norm1, z)                                                  # :237-238
@@ -262,9 +263,10 @@ class TransformerDecoderLayer(nn.Module):
         k = ops.add3(_lin(self.sa_kcontent_proj, tgt), _lin(self.sa_ktime_proj, time_embed),
                      _lin(self.sa_kpos_proj, query_pos))
         v = _lin(self.sa_v_proj, tgt)
-        qp = ops.linear(q, W[:D], Bi[:D])                                                    # nn.MHA in-proj :341
-        kp_ = ops.linear(k, W[D:2 * D], Bi[D:2 * D])
-        vp = ops.linear(v, W[2 * D:], Bi[2 * D:])
+        (Wq, Wk, Wv), (Bq, Bk, Bv) = ops.split_rows(W, (D, D, D)), ops.split_rows(Bi, (D, D, D))
+        qp = ops.linear(q, Wq, Bq)                                                           # nn.MHA in-proj :341
+        kp_ = ops.linear(k, Wk, Bk)
+        vp = ops.linear(v, Wv, Bv)
         a, _ = ops.mha_self(qp[None], kp_[None], vp[None], None, hd ** -0.5, drop_p=p)
         tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
 
@@ -341,19 +343,20 @@ class TimeDecoderLayer(nn.Module):
         self.nhead = nhead
         self.dropout_p = dropout
 
-    def run(self, tgt, kc, vv, kpm, query_pos, qpos_time):
-        """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory."""
+    def run(self, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
+        """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory; Wcq/Bcq: the query
+        rows of cross_attn_image's packed in-projection (split once in TimeDecoder.run)."""
         T, D = tgt.shape
         hd = D // self.nhead
         p = self.dropout_p if self.training else 0.0
-        W, Bi = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        (Wqk, Wv), (Bqk, Bv) = (ops.split_rows(self.self_attn.in_proj_weight, (2 * D, D)),
+                                ops.split_rows(self.self_attn.in_proj_bias, (2 * D, D)))
         qk_in = ops.add(tgt, qpos_time)                                                      # :602
-        qk = ops.linear(qk_in, W[:2 * D], Bi[:2 * D])
-        v = ops.linear(tgt, W[2 * D:], Bi[2 * D:])
+        qk = ops.linear(qk_in, Wqk, Bqk)
+        v = ops.linear(tgt, Wv, Bv)
         a, w = ops.mha_self_packed(qk[None], v[None], None, hd ** -0.5, need_weights=True, drop_p=p)   # :604-610
         tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
-        Wc, Bc = self.cross_attn_image.in_proj_weight, self.cross_attn_image.in_proj_bias
-        qc = ops.linear(ops.add(tgt, query_pos), Wc[:D], Bc[:D])                             # :633-634
+        qc = ops.linear(ops.add(tgt, query_pos), Wcq, Bcq)                                   # :633-634
         a = ops.attn_q1(qc, None, kc, None, vv, kpm, hd ** -0.5, drop_p=p)
         tgt = _ln(self.norm3, _lin_res(self.cross_attn_image.out_proj.weight, self.cross_attn_image.out_proj.bias,
                                        a, tgt, p))                                            # :653-654
@@ -375,17 +378,19 @@ class TimeDecoder(nn.Module):
         T = query_pos.shape[0]
         D = self.d_model
         nl = len(self.layers)
-        Wk = torch.cat([l.cross_attn_image.in_proj_weight[D:2 * D] for l in self.layers], dim=0)
-        Bk = torch.cat([l.cross_attn_image.in_proj_bias[D:2 * D] for l in self.layers], dim=0)
-        Wv = torch.cat([l.cross_attn_image.in_proj_weight[2 * D:] for l in self.layers], dim=0)
-        Bv = torch.cat([l.cross_attn_image.in_proj_bias[2 * D:] for l in self.layers], dim=0)
+        wparts = [ops.split_rows(l.cross_attn_image.in_proj_weight, (D, D, D)) for l in self.layers]
+        bparts = [ops.split_rows(l.cross_attn_image.in_proj_bias, (D, D, D)) for l in self.layers]
+        Wk = torch.cat([w[1] for w in wparts], dim=0)
+        Bk = torch.cat([b[1] for b in bparts], dim=0)
+        Wv = torch.cat([w[2] for w in wparts], dim=0)
+        Bv = torch.cat([b[2] for b in bparts], dim=0)
         kc = ops.split_cols(ops.linear(mem_pos, Wk, Bk), nl)
         vv = ops.split_cols(ops.linear(memory, Wv, Bv), nl)
         out = torch.zeros(T, self.d_model, device=memory.device)
         qpos_time = ops.add_const(query_pos, time_pos)                                       # query_pos + time :602
         inter, ws = [], []
         for i, layer in enumerate(self.layers):
-            out, w = layer.run(out, kc[i], vv[i], kpm, query_pos, qpos_time)
+            out, w = layer.run(out, kc[i], vv[i], kpm, query_pos, qpos_time, wparts[i][0], bparts[i][0])
             inter.append(_ln(self.norm, out))
             ws.append(w)
         return torch.stack(inter), torch.stack(ws)

@@ -711,6 +711,35 @@ def split_cols(x, n):
     return SplitColsFn.apply(x, n)
 
 
+class SplitRowsFn(Function):
+    """Row blocks of a packed parameter (nn.MultiheadAttention's in_proj_weight [3D, D] / in_proj_bias [3D]) as
+    views.  Plain slicing costs, per slice and step, a full-size zero fill + a copy in SliceBackward and an add to
+    merge the slices' gradients (~500 launches per step over the 24 attention layers); here the backward is ONE
+    concatenation of the per-block gradients."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        assert sum(sizes) == x.shape[0]
+        ctx.sizes = sizes
+        ctx.rest = tuple(x.shape[1:])
+        ctx.dev, ctx.dt = x.device, x.dtype
+        out, a = [], 0
+        for n in sizes:
+            out.append(x[a:a + n])
+            a += n
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        parts = [g if g is not None else torch.zeros(n, *ctx.rest, device=ctx.dev, dtype=ctx.dt)
+                 for g, n in zip(gs, ctx.sizes)]
+        return torch.cat(parts, dim=0), None
+
+
+def split_rows(x, sizes):
+    return SplitRowsFn.apply(x, tuple(sizes))
+
+
 def attn_q1(q1, q2, k1, k2, v, kpm, scale, drop_p=0.0):
     return AttnQ1Fn.apply(q1, q2, k1, k2, v, kpm, scale, drop_p)
 

@@ -77,6 +77,9 @@ class STCATNet(nn.Module):
         if self.use_actioness:
             act = self.action_embed(time_hs)[:, None]                                        # :103
             out["pred_actioness"] = act[-1]
+        # the per-layer tensors, still stacked [layers, ...]: VideoSTGLoss evaluates all layers in one vectorised pass
+        # and would otherwise re-stack what the loop below unstacks (and pay ~70 select-backward/add launches)
+        out["_stacked"] = {"pred_boxes": coord, "pred_sted": sted, "weights": weights, "pred_actioness": act}
         if self.use_aux_loss:                                                                # :106-119
             out["aux_outputs"] = []
             for i in range(coord.shape[0] - 1):
@@ -184,7 +187,11 @@ class VideoSTGLoss(nn.Module):
         layers = list(aux) + [outputs]                                              # main output last
         nl = len(layers)
         # criterion.py:168-171 — the reference overwrites pred_boxes with the GT-span rows
-        boxes = torch.stack([l["pred_boxes"] for l in layers])[:, plan.rows]        # [nl, nbox, 4]
+        stk = outputs.get("_stacked")
+        if stk is not None and stk["pred_boxes"].shape[0] != nl:
+            stk = None                                                               # (aux losses disabled)
+        _st = lambda key: stk[key] if stk is not None else torch.stack([l[key] for l in layers])  # noqa: E731
+        boxes = _st("pred_boxes")[:, plan.rows]                                     # [nl, nbox, 4]
         for i, l in enumerate(layers):
             l["pred_boxes"] = boxes[i]
         num_boxes = plan.num_boxes(dev)
@@ -195,17 +202,17 @@ class VideoSTGLoss(nn.Module):
             giou = paired_giou(box_cxcywh_to_xyxy(boxes.reshape(-1, 4)), box_cxcywh_to_xyxy(tgt.reshape(-1, 4)))
             vec["loss_giou"] = (1 - giou).view(nl, -1).sum(1) / num_boxes
         if "sted" in self.losses:
-            sted = torch.stack([l["pred_sted"] for l in layers])                    # [nl,b,T,2]
+            sted = _st("pred_sted")                                                 # [nl,b,T,2]
             sted = sted.masked_fill(~plan.time_mask[None, :, :, None], -1e32)
             prob = sted.softmax(2)
             kl = prob * ((prob + 1e-6) / plan.dist[None]).log() * plan.time_mask_f[None, :, :, None]
             vec["loss_sted"] = kl.sum(3).mean((1, 2))
         if "guided_attn" in self.losses:
-            w = torch.stack([l["weights"] for l in layers])                         # [nl,b,T,T]
+            w = _st("weights")                                                      # [nl,b,T,T]
             la = (-(1 - w + 1e-6).log()).masked_fill(plan.pos_or_pad[None, :, :, None], 0)
             vec["loss_guided_attn"] = (la.sum(3) / plan.nb_neg[None, :, None]).sum(2).mean(1)
         if "actioness" in self.losses:
-            pa = torch.stack([l["pred_actioness"] for l in layers]).squeeze(-1)     # [nl,b,T]
+            pa = _st("pred_actioness").squeeze(-1)                                  # [nl,b,T]
             la = F.binary_cross_entropy_with_logits(pa, plan.actioness[None].expand(nl, -1, -1),
                                                     weight=plan.act_weight[None].expand(nl, -1, -1), reduction="none")
             vec["loss_actioness"] = (la * plan.time_mask_f[None]).mean((1, 2))
