@@ -101,11 +101,15 @@ int stcat_small_linear_bwd(const float* g, const float* x, const float* w, float
                            int N, int K, void* stream);
 /* out[N] (caller-zeroed) += sum_m a[m,n] * (b ? b[m,n] : 1) */
 int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);
-/* LayerNorm over 256 features of (x + res); saves mean / rstd per row */
+/* LayerNorm over 256 features of (res + dropout_p(x)); saves mean / rstd per row.  The (drop_p, drop_seed,
+ * drop_offset, drop_base) quadruple is the dropout of the residual branch (see "dropout" below; drop_p = 0: plain
+ * x + res).  Backward: dz = gradient of res (and of x when drop_p = 0), dx (may be NULL when drop_p = 0) = mask * dz. */
 int stcat_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                        float* mean, float* rstd, int M, int D, float eps, void* stream);
+                        float* mean, float* rstd, int M, int D, float eps, float drop_p, long drop_seed,
+                        long drop_offset, const long* drop_base, void* stream);
 int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
-                        const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D, void* stream);
+                        const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int M, int D,
+                        float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
 /* element-wise glue; op codes STCAT_EW_* below; b indexed modulo bmod */
 int stcat_ew(int op, const float* a, const float* b, const float* c, float* out, long n, long bmod, float alpha,
              float beta, void* stream);

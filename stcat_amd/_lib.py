@@ -36,8 +36,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_small_linear_fwd": "ppppiiis",
     "stcat_small_linear_bwd": "ppppppiiis",
     "stcat_colsum": "pppiis",
-    "stcat_layernorm_fwd": "pppppppiifs",
-    "stcat_layernorm_bwd": "pppppppppiis",
+    "stcat_layernorm_fwd": "pppppppiif" + "fllps",
+    "stcat_layernorm_bwd": "ppppppppppii" + "fllps",
     "stcat_ew": "ipppp" + "llffs",
     "stcat_dropout": "ppplfllps",
     "stcat_mha_self_fwd": "ppppppiiiiiiif" + "fllps",

@@ -10,13 +10,21 @@
 // LayerNorm over D = 256 (torch.nn.LayerNorm(256), eps 1e-5: modal_encoder.py:218-219,
 // query_decoder.py:296-299, 573-576).  One wave per row, one float4 per lane.
 // ---------------------------------------------------------------------------------
+// y = LayerNorm(res + dropout(x)): the dropout of the residual branch (modal_encoder.py:237-240 and friends) is
+// applied in-register from its counter-based mask; drop.thresh == 0 means no dropout
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* x, const float* res, const float* gamma,
                                                            const float* beta, float* y, float* mean, float* rstd,
-                                                           int M, float eps) {
+                                                           int M, float eps, DropParams drop) {
+  drop = stcat_drop_resolve(drop);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 g = stcat_ld4(gamma + lane * 4), bt = stcat_ld4(beta + lane * 4);
   for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
     float4 v = stcat_ld4(x + (long)row * 256 + lane * 4);
+    if (drop.thresh) {
+      const unsigned long long c0 = (unsigned long long)row * 256 + lane * 4;
+      v.x *= stcat_drop_mul(drop, c0); v.y *= stcat_drop_mul(drop, c0 + 1);
+      v.z *= stcat_drop_mul(drop, c0 + 2); v.w *= stcat_drop_mul(drop, c0 + 3);
+    }
     if (res) {
       const float4 r = stcat_ld4(res + (long)row * 256 + lane * 4);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -35,15 +43,25 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* x, cons
 }
 
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; dgamma += dy * xhat, dbeta += dy
+// with dropout: dz is the gradient of the residual input, dx = mask * dz the gradient of the dropped branch
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* dy, const float* x, const float* res,
                                                            const float* gamma, const float* mean, const float* rstd,
-                                                           float* dz, float* dgamma, float* dbeta, int M) {
+                                                           float* dz, float* dx, float* dgamma, float* dbeta, int M,
+                                                           DropParams drop) {
+  drop = stcat_drop_resolve(drop);
   __shared__ float red[2][4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 g = stcat_ld4(gamma + lane * 4);
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
   for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
     float4 v = stcat_ld4(x + (long)row * 256 + lane * 4);
+    float4 dm = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (drop.thresh) {
+      const unsigned long long c0 = (unsigned long long)row * 256 + lane * 4;
+      dm = make_float4(stcat_drop_mul(drop, c0), stcat_drop_mul(drop, c0 + 1), stcat_drop_mul(drop, c0 + 2),
+                       stcat_drop_mul(drop, c0 + 3));
+      v.x *= dm.x; v.y *= dm.y; v.z *= dm.z; v.w *= dm.w;
+    }
     if (res) {
       const float4 r = stcat_ld4(res + (long)row * 256 + lane * 4);
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -54,9 +72,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* dy, con
     const float gx = d.x * g.x, gy = d.y * g.y, gz = d.z * g.z, gw = d.w * g.w;
     const float c1 = stcat_wave_sum(gx + gy + gz + gw) * (1.f / 256.f);
     const float c2 = stcat_wave_sum(gx * hx + gy * hy + gz * hz + gw * hw) * (1.f / 256.f);
-    stcat_st4(dz + (long)row * 256 + lane * 4,
-              make_float4(rs * (gx - c1 - hx * c2), rs * (gy - c1 - hy * c2), rs * (gz - c1 - hz * c2),
-                          rs * (gw - c1 - hw * c2)));
+    const float4 dzv = make_float4(rs * (gx - c1 - hx * c2), rs * (gy - c1 - hy * c2), rs * (gz - c1 - hz * c2),
+                                   rs * (gw - c1 - hw * c2));
+    stcat_st4(dz + (long)row * 256 + lane * 4, dzv);
+    if (dx) stcat_st4(dx + (long)row * 256 + lane * 4, make_float4(dzv.x * dm.x, dzv.y * dm.y, dzv.z * dm.z, dzv.w * dm.w));
     ag.x += d.x * hx; ag.y += d.y * hy; ag.z += d.z * hz; ag.w += d.w * hw;
     ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
   }

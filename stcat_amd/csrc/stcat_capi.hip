@@ -488,18 +488,21 @@ int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void*
 }
 
 int stcat_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
-                        float* mean, float* rstd, int M, int D, float eps, void* stream) {
+                        float* mean, float* rstd, int M, int D, float eps, float drop_p, long drop_seed,
+                        long drop_offset, const long* drop_base, void* stream) {
   if (D != 256) return fail("layernorm: D must be 256 (got %d)", D);
   STCAT_LAUNCH(layernorm_fwd_kernel, dim3(grid_for(M, 4, 2048)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-               beta, y, mean, rstd, M, eps);
+               beta, y, mean, rstd, M, eps, stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base));
   return launch_status();
 }
 
 int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const float* gamma, const float* mean,
-                        const float* rstd, float* dz, float* dgamma, float* dbeta, int M, int D, void* stream) {
+                        const float* rstd, float* dz, float* dx, float* dgamma, float* dbeta, int M, int D,
+                        float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (D != 256) return fail("layernorm: D must be 256 (got %d)", D);
+  if (drop_p > 0.f && !dx) return fail("layernorm_bwd: dropout needs the dx output");
   STCAT_LAUNCH(layernorm_bwd_kernel, dim3(grid_for(M, 16, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, res, gamma,
-               mean, rstd, dz, dgamma, dbeta, M);
+               mean, rstd, dz, dx, dgamma, dbeta, M, stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base));
   return launch_status();
 }
 

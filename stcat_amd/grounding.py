@@ -64,21 +64,23 @@ def _lin(m: nn.Linear, x, res=None, relu=False):
     return ops.linear(x, m.weight, m.bias, res=res, relu=relu)
 
 
-def _lin_res(w, b, x, res, p: float):
-    """res + dropout_p(x W^T + b): the residual rides in the GEMM epilogue when dropout is off (eval)."""
-    if p > 0.0:
-        return ops.dropout_add(ops.linear(x, w, b), res, p)
-    return ops.linear(x, w, b, res=res)
-
-
-def _ffn(layer, x, p: float):
-    """x + dropout(linear2(dropout(relu(linear1 x))))  (modal_encoder.py:239-240; query_decoder.py:435-436, 657-658)"""
-    h = ops.dropout(_lin(layer.linear1, x, relu=True), p)
-    return _lin_res(layer.linear2.weight, layer.linear2.bias, h, x, p)
-
-
 def _ln(m: nn.LayerNorm, x):
     return ops.layer_norm(x, m.weight, m.bias, eps=m.eps)
+
+
+def _ln_res(m: nn.LayerNorm, w, b, x, res, p: float):
+    """LayerNorm(res + dropout_p(x W^T + b)).  Eval (p = 0): the residual rides in the GEMM epilogue.  Train: the
+    dropout and the residual add happen inside the LayerNorm kernel (no separate dropout pass)."""
+    if p > 0.0:
+        return ops.layer_norm(ops.linear(x, w, b), m.weight, m.bias, res=res, eps=m.eps, drop_p=p)
+    return ops.layer_norm(ops.linear(x, w, b, res=res), m.weight, m.bias, eps=m.eps)
+
+
+def _ffn_ln(norm: nn.LayerNorm, layer, x, p: float):
+    """norm(x + dropout(linear2(dropout(relu(linear1 x)))))  (modal_encoder.py:239-241; query_decoder.py:435-437,
+    657-659)"""
+    h = ops.dropout(_lin(layer.linear1, x, relu=True), p)
+    return _ln_res(norm, layer.linear2.weight, layer.linear2.bias, h, x, p)
 
 
 def _xavier(module: nn.Module):
@@ -114,9 +116,8 @@ class TransformerEncoderLayer(nn.Module):
         qk = ops.linear(qk_in, Wqk, Bqk)                                        # packed q|k projection
         v = ops.linear(x, Wv, Bv)                                               # value = src         :236
         a, _ = ops.mha_self_packed(qk, v, kpm, (D // self.nhead) ** -0.5, drop_p=p)
-        z = _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a, x, p)
-        x = _ln(self.norm1, z)                                                  # :237-238
-        return _ln(self.norm2, _ffn(self, x, p))                                # :239-241
+        x = _ln_res(self.norm1, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a, x, p)   # :237-238
+        return _ffn_ln(self.norm2, self, x, p)                                  # :239-241
 
 
 class SpatialTemporalEncoder(nn.Module):
@@ -268,7 +269,7 @@ class TransformerDecoderLayer(nn.Module):
         kp_ = ops.linear(k, Wk, Bk)
         vp = ops.linear(v, Wv, Bv)
         a, _ = ops.mha_self(qp[None], kp_[None], vp[None], None, hd ** -0.5, drop_p=p)
-        tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
+        tgt = _ln_res(self.norm1, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p)
 
         qc = _lin(self.ca_qcontent_proj, tgt)
         if first:                                                                            # :360-366
@@ -277,8 +278,8 @@ class TransformerDecoderLayer(nn.Module):
             kc = ops.add(kc.contiguous(), kpos)
         qs = _lin(self.ca_qpos_sine_proj, query_sine)                                        # :369
         a = ops.attn_q1(qc, qs, kc, kpos, vv, kpm, (2 * hd) ** -0.5, drop_p=p)               # :368-409
-        tgt = _ln(self.norm3, _lin_res(self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias, a, tgt, p))  # :431
-        return _ln(self.norm4, _ffn(self, tgt, p))                                           # :435-437
+        tgt = _ln_res(self.norm3, self.cross_attn.out_proj.weight, self.cross_attn.out_proj.bias, a, tgt, p)  # :431
+        return _ffn_ln(self.norm4, self, tgt, p)                                             # :435-437
 
 
 class TransformerDecoder(nn.Module):
@@ -355,12 +356,12 @@ class TimeDecoderLayer(nn.Module):
         qk = ops.linear(qk_in, Wqk, Bqk)
         v = ops.linear(tgt, Wv, Bv)
         a, w = ops.mha_self_packed(qk[None], v[None], None, hd ** -0.5, need_weights=True, drop_p=p)   # :604-610
-        tgt = _ln(self.norm1, _lin_res(self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p))
+        tgt = _ln_res(self.norm1, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, a[0], tgt, p)
         qc = ops.linear(ops.add(tgt, query_pos), Wcq, Bcq)                                   # :633-634
         a = ops.attn_q1(qc, None, kc, None, vv, kpm, hd ** -0.5, drop_p=p)
-        tgt = _ln(self.norm3, _lin_res(self.cross_attn_image.out_proj.weight, self.cross_attn_image.out_proj.bias,
-                                       a, tgt, p))                                            # :653-654
-        return _ln(self.norm4, _ffn(self, tgt, p)), w                                        # :657-659
+        tgt = _ln_res(self.norm3, self.cross_attn_image.out_proj.weight, self.cross_attn_image.out_proj.bias,
+                      a, tgt, p)                                                             # :653-654
+        return _ffn_ln(self.norm4, self, tgt, p), w                                          # :657-659
 
 
 class TimeDecoder(nn.Module):

@@ -254,8 +254,12 @@ def linear(x, w, b=None, res=None, relu=False):
 # LayerNorm(x + res)
 # ------------------------------------------------------------------------------------
 class LayerNormFn(Function):
+    """y = LayerNorm(res + dropout_p(x)) over 256 features (p = 0: plain x + res).  The residual branch's dropout
+    (modal_encoder.py:237-240; query_decoder.py:344, 431, 436, 612, 653, 658) rides inside the kernel: mask from the
+    counter stream in forward, regenerated in backward — no separate dropout pass over the activations."""
+
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, drop_p=0.0):
         shp = x.shape
         D = shp[-1]
         x2 = _c(x.reshape(-1, D))
@@ -265,10 +269,14 @@ class LayerNormFn(Function):
         y = torch.empty_like(x2)
         mean = _empty(x2, M)
         rstd = _empty(x2, M)
+        drop = (0.0, 0, 0, None)
+        if drop_p > 0.0:
+            drop = (float(drop_p),) + _dropout_stream.take(x2.numel(), x2.device)
         L.call("stcat_layernorm_fwd", x2.data_ptr(), L._ptr(r2), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-               mean.data_ptr(), rstd.data_ptr(), M, D, eps, L.stream_of(x2))
+               mean.data_ptr(), rstd.data_ptr(), M, D, eps, *drop, L.stream_of(x2))
         ctx.save_for_backward(x2, r2, gamma, mean, rstd)
         ctx.xshape = shp
+        ctx.drop = drop
         return y.view(shp)
 
     @staticmethod
@@ -277,16 +285,19 @@ class LayerNormFn(Function):
         M, D = x2.shape
         g = _c(dy.reshape(M, D))
         dz = torch.empty_like(x2)
+        dx = torch.empty_like(x2) if ctx.drop[0] > 0.0 else None
         dgam = _zeros(x2, D)
         dbet = _zeros(x2, D)
         L.call("stcat_layernorm_bwd", g.data_ptr(), x2.data_ptr(), L._ptr(r2), gamma.data_ptr(), mean.data_ptr(),
-               rstd.data_ptr(), dz.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), M, D, L.stream_of(g))
+               rstd.data_ptr(), dz.data_ptr(), L._ptr(dx), dgam.data_ptr(), dbet.data_ptr(), M, D, *ctx.drop,
+               L.stream_of(g))
         dzv = dz.view(ctx.xshape)
-        return dzv, (dzv if r2 is not None else None), dgam, dbet, None
+        dxv = dx.view(ctx.xshape) if dx is not None else dzv
+        return dxv, (dzv if r2 is not None else None), dgam, dbet, None, None
 
 
-def layer_norm(x, gamma, beta, res=None, eps: float = 1e-5):
-    return LayerNormFn.apply(x, res, gamma, beta, eps)
+def layer_norm(x, gamma, beta, res=None, eps: float = 1e-5, drop_p: float = 0.0):
+    return LayerNormFn.apply(x, res, gamma, beta, eps, drop_p)
 
 
 # ------------------------------------------------------------------------------------

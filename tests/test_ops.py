@@ -389,8 +389,33 @@ def _q1_dropout_case(dev, B, S, H, pdrop=0.25):
         close(t.grad, r.grad, TOL, tag + " " + nm)
 
 
+def _layernorm_dropout_case(dev, M, pdrop=0.2):
+    x, r = rnd(M, 256, seed=1), rnd(M, 256, seed=2)
+    gam, bet = rnd(256, seed=3) + 1.0, rnd(256, seed=4)
+    gy = rnd(M, 256, seed=5)
+    ops.manual_seed(99)
+    seed, off = ops.dropout_stream_state()
+    m = _mask_of(pdrop, seed, off, M * 256).view(M, 256)
+    xr, rr, gr, br = [t.clone().requires_grad_(True) for t in (x, r, gam, bet)]
+    ref = F.layer_norm(rr + xr * m, (256,), gr, br, 1e-5)
+    ref.backward(gy)
+    xd, rd, gd, bd = [t.to(dev).requires_grad_(True) for t in (x, r, gam, bet)]
+    y = ops.layer_norm(xd, gd, bd, res=rd, drop_p=pdrop)
+    y.backward(gy.to(dev))
+    tag = f"layernorm+dropout M{M}"
+    close(y, ref, TOL, tag + " y")
+    close(xd.grad, xr.grad, TOL, tag + " dx")
+    close(rd.grad, rr.grad, TOL, tag + " dres")
+    close(gd.grad, gr.grad, TOL, tag + " dgamma")
+    close(bd.grad, br.grad, TOL, tag + " dbeta")
+    assert (xd.grad == 0).float().mean().item() > pdrop / 2      # dropped positions get no gradient
+
+
 @both
 def _dropout(dev, big):
+    _layernorm_dropout_case(dev, 37)
+    if big:
+        _layernorm_dropout_case(dev, 13248)
     _dropout_elementwise(dev, 4096 + 3, with_res=True)
     _dropout_elementwise(dev, 1024, with_res=False)
     _mha_dropout_case(dev, 2, 37, 2, need_w=False)
