@@ -28,7 +28,7 @@ def test_build_and_symbols():
 def test_invalid_arguments_report_errors():
     entry.build()
     lib = L._bind(ctypes.CDLL(entry.LIB))
-    assert lib.stcat_layernorm_fwd(None, None, None, None, None, None, None, 4, 128, 1e-5, None) == -1
+    assert lib.stcat_layernorm_fwd(None, None, None, None, None, None, None, 4, 128, 1e-5, 0.0, 0, 0, None, None) == -1
     assert b"256" in lib.stcat_last_error()
     assert lib.stcat_linear_fwd(None, None, None, None, None, 8, 60, 16, 16, 60, 0, 0, 0, 0, None) == -1
     assert lib.stcat_debug_force_tile(32, 32) == -1
