@@ -25,6 +25,9 @@ SHAPES = [
     ("l4.conv3 1x1 512>2048", 64, 14, 14, 512, 2048, 1, 1, 0),
     ("enc.ffn1 256>2048", 1, 1, 13248, 256, 2048, 1, 1, 0),
     ("enc.qk 256>512", 1, 1, 13248, 256, 512, 1, 1, 0),
+    ("enc.out 256>256", 1, 1, 13248, 256, 256, 1, 1, 0),
+    ("enc.ffn2 2048>256", 1, 1, 13248, 2048, 256, 1, 1, 0),
+    ("dec.kv 256>1536", 1, 1, 13248, 256, 1536, 1, 1, 0),
 ]
 
 
