@@ -341,14 +341,16 @@ struct AttnQ1Params {
 
 #define STCAT_Q1_MAXC 4  // S <= 256
 
+// One workgroup per (frame, head); its four waves take 64 keys each (S <= 256), so 4x as many waves are in flight
+// as with one wave per (frame, head) — the kernel is a latency-bound gather of 128-byte key / value rows
+// (3 x 13.5 MB per layer at C3), and memory-level parallelism is what it needs.
 __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
   p.drop = stcat_drop_resolve(p.drop);
-  __shared__ float ps[4][STCAT_Q1_MAXC * 64];
+  __shared__ float ps[STCAT_Q1_MAXC * 64];
+  __shared__ float red[2][4];
+  __shared__ float opart[4][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int bh_raw = blockIdx.x * 4 + w;
-  const bool live = bh_raw < p.B * p.H;
-  const int bh = live ? bh_raw : 0;
-  const int b = bh / p.H, h = bh % p.H;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   float qa[32], qb[32];
   STCAT_UNROLL
   for (int c = 0; c < 8; ++c) {
@@ -357,65 +359,56 @@ __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
     float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
   }
-  float sc[STCAT_Q1_MAXC];
-  float mx = STCAT_NEG_INF;
-  STCAT_UNROLL
-  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
-    const int s = c * 64 + lane;
-    float val = STCAT_NEG_INF;
-    if (s < p.S && !(p.kpm && p.kpm[(long)b * p.S + s])) {
-      const float* kr = p.k1 + ((long)b * p.S + s) * p.ldk + h * 32;
-      float dot = 0.f;
+  const int s = w * 64 + lane;
+  float val = STCAT_NEG_INF;
+  if (s < p.S && !(p.kpm && p.kpm[(long)b * p.S + s])) {
+    const float* kr = p.k1 + ((long)b * p.S + s) * p.ldk + h * 32;
+    float dot = 0.f;
+    STCAT_UNROLL
+    for (int d4 = 0; d4 < 8; ++d4) {
+      float4 kv = stcat_ld4(kr + d4 * 4);
+      dot += kv.x * qa[d4 * 4] + kv.y * qa[d4 * 4 + 1] + kv.z * qa[d4 * 4 + 2] + kv.w * qa[d4 * 4 + 3];
+    }
+    if (p.k2) {
+      const float* kr2 = p.k2 + ((long)b * p.S + s) * p.ldk + h * 32;
       STCAT_UNROLL
       for (int d4 = 0; d4 < 8; ++d4) {
-        float4 kv = stcat_ld4(kr + d4 * 4);
-        dot += kv.x * qa[d4 * 4] + kv.y * qa[d4 * 4 + 1] + kv.z * qa[d4 * 4 + 2] + kv.w * qa[d4 * 4 + 3];
+        float4 kv = stcat_ld4(kr2 + d4 * 4);
+        dot += kv.x * qb[d4 * 4] + kv.y * qb[d4 * 4 + 1] + kv.z * qb[d4 * 4 + 2] + kv.w * qb[d4 * 4 + 3];
       }
-      if (p.k2) {
-        const float* kr2 = p.k2 + ((long)b * p.S + s) * p.ldk + h * 32;
-        STCAT_UNROLL
-        for (int d4 = 0; d4 < 8; ++d4) {
-          float4 kv = stcat_ld4(kr2 + d4 * 4);
-          dot += kv.x * qb[d4 * 4] + kv.y * qb[d4 * 4 + 1] + kv.z * qb[d4 * 4 + 2] + kv.w * qb[d4 * 4 + 3];
-        }
-      }
-      val = dot * p.scale;
     }
-    sc[c] = val;
-    mx = fmaxf(mx, val);
+    val = dot * p.scale;
   }
-  mx = stcat_wave_max(mx);
-  float sum = 0.f;
-  STCAT_UNROLL
-  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
-    sc[c] = __expf(sc[c] - mx);
-    sum += sc[c];
-  }
-  sum = stcat_wave_sum(sum);
-  const float inv = 1.f / sum;
-  STCAT_UNROLL
-  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
-    const int s = c * 64 + lane;
-    const float pr = sc[c] * inv;
-    ps[w][s] = pr * stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
-    if (live && s < p.S) p.P[(long)bh * p.S + s] = pr;
-  }
+  const float mw = stcat_wave_max(val);
+  if (lane == 0) red[0][w] = mw;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  const float e = __expf(val - mx);
+  const float sw = stcat_wave_sum(e);
+  if (lane == 0) red[1][w] = sw;
+  __syncthreads();
+  const float inv = 1.f / (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  const float pr = e * inv;
+  ps[s] = pr * stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
+  if (s < p.S) p.P[(long)bh * p.S + s] = pr;
   __syncthreads();
   float o = 0.f;
   const float* vb = p.v + (long)b * p.S * p.ldv + h * 32 + l31;
-  for (int s = hi; s < p.S; s += 2) o += ps[w][s] * vb[(long)s * p.ldv];
+  const int s_end = min(p.S, w * 64 + 64);
+  for (int k = w * 64 + hi; k < s_end; k += 2) o += ps[k] * vb[(long)k * p.ldv];
   o += __shfl_xor(o, 32);
-  if (live && hi == 0) p.out[(long)b * p.H * 32 + h * 32 + l31] = o;
+  if (hi == 0) opart[w][l31] = o;
+  __syncthreads();
+  if (t < 32) p.out[(long)b * p.H * 32 + h * 32 + t] = opart[0][t] + opart[1][t] + opart[2][t] + opart[3][t];
 }
 
 __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
   p.drop = stcat_drop_resolve(p.drop);
-  __shared__ float dss[4][STCAT_Q1_MAXC * 64];
+  __shared__ float dss[STCAT_Q1_MAXC * 64];
+  __shared__ float red[4];
+  __shared__ float qpart[2][4][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int bh_raw = blockIdx.x * 4 + w;
-  const bool live = bh_raw < p.B * p.H;
-  const int bh = live ? bh_raw : 0;
-  const int b = bh / p.H, h = bh % p.H;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
   const int HD = p.H * 32;
   float go[32], qa[32], qb[32];
   STCAT_UNROLL
@@ -427,67 +420,58 @@ __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
     float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
   }
-  float pr[STCAT_Q1_MAXC], dp[STCAT_Q1_MAXC], dm[STCAT_Q1_MAXC];
-  float delta = 0.f;
-  STCAT_UNROLL
-  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
-    const int s = c * 64 + lane;
-    pr[c] = 0.f;
-    dp[c] = 0.f;
-    dm[c] = 1.f;
-    if (s < p.S) {
-      pr[c] = p.P[(long)bh * p.S + s];
-      const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
-      float dot = 0.f;
-      STCAT_UNROLL
-      for (int d4 = 0; d4 < 8; ++d4) {
-        float4 vv = stcat_ld4(vr + d4 * 4);
-        dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
-      }
-      dm[c] = stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
-      dp[c] = dot * dm[c];  // dP = M' * (dO . V)
-      delta += pr[c] * dp[c];
+  const int s = w * 64 + lane;
+  float pr = 0.f, dp = 0.f, dm = 1.f;
+  if (s < p.S) {
+    pr = p.P[(long)bh * p.S + s];
+    const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
+    float dot = 0.f;
+    STCAT_UNROLL
+    for (int d4 = 0; d4 < 8; ++d4) {
+      float4 vv = stcat_ld4(vr + d4 * 4);
+      dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
     }
+    dm = stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
+    dp = dot * dm;  // dP = M' * (dO . V)
   }
-  delta = stcat_wave_sum(delta);
-  STCAT_UNROLL
-  for (int c = 0; c < STCAT_Q1_MAXC; ++c) {
-    const int s = c * 64 + lane;
-    const float ds = pr[c] * (dp[c] - delta) * p.scale;
-    const float pd = pr[c] * dm[c];  // dV = P' dO
-    dss[w][s] = ds;
-    if (live && s < p.S) {
-      float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
-      float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
+  const float dw = stcat_wave_sum(pr * dp);
+  if (lane == 0) red[w] = dw;
+  __syncthreads();
+  const float delta = red[0] + red[1] + red[2] + red[3];
+  const float ds = pr * (dp - delta) * p.scale;
+  const float pd = pr * dm;  // dV = P' dO
+  dss[s] = ds;
+  if (s < p.S) {
+    float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
+    float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
+    STCAT_UNROLL
+    for (int d4 = 0; d4 < 8; ++d4) {
+      stcat_st4(gv + d4 * 4, make_float4(pd * go[d4 * 4], pd * go[d4 * 4 + 1], pd * go[d4 * 4 + 2], pd * go[d4 * 4 + 3]));
+      stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2], ds * qa[d4 * 4 + 3]));
+    }
+    if (p.dk2) {
+      float* gk2 = p.dk2 + ((long)b * p.S + s) * HD + h * 32;
       STCAT_UNROLL
-      for (int d4 = 0; d4 < 8; ++d4) {
-        stcat_st4(gv + d4 * 4, make_float4(pd * go[d4 * 4], pd * go[d4 * 4 + 1], pd * go[d4 * 4 + 2],
-                                           pd * go[d4 * 4 + 3]));
-        stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2],
-                                            ds * qa[d4 * 4 + 3]));
-      }
-      if (p.dk2) {
-        float* gk2 = p.dk2 + ((long)b * p.S + s) * HD + h * 32;
-        STCAT_UNROLL
-        for (int d4 = 0; d4 < 8; ++d4)
-          stcat_st4(gk2 + d4 * 4, make_float4(ds * qb[d4 * 4], ds * qb[d4 * 4 + 1], ds * qb[d4 * 4 + 2],
-                                              ds * qb[d4 * 4 + 3]));
-      }
+      for (int d4 = 0; d4 < 8; ++d4)
+        stcat_st4(gk2 + d4 * 4, make_float4(ds * qb[d4 * 4], ds * qb[d4 * 4 + 1], ds * qb[d4 * 4 + 2], ds * qb[d4 * 4 + 3]));
     }
   }
   __syncthreads();
   float a1 = 0.f, a2 = 0.f;
   const float* k1b = p.k1 + (long)b * p.S * p.ldk + h * 32 + l31;
   const float* k2b = p.k2 ? p.k2 + (long)b * p.S * p.ldk + h * 32 + l31 : nullptr;
-  for (int s = hi; s < p.S; s += 2) {
-    const float ds = dss[w][s];
-    a1 += ds * k1b[(long)s * p.ldk];
-    if (k2b) a2 += ds * k2b[(long)s * p.ldk];
+  const int s_end = min(p.S, w * 64 + 64);
+  for (int k = w * 64 + hi; k < s_end; k += 2) {
+    const float d = dss[k];
+    a1 += d * k1b[(long)k * p.ldk];
+    if (k2b) a2 += d * k2b[(long)k * p.ldk];
   }
   a1 += __shfl_xor(a1, 32);
   a2 += __shfl_xor(a2, 32);
-  if (live && hi == 0) {
-    p.dq1[(long)b * HD + h * 32 + l31] = a1;
-    if (p.dq2) p.dq2[(long)b * HD + h * 32 + l31] = a2;
+  if (hi == 0) { qpart[0][w][l31] = a1; qpart[1][w][l31] = a2; }
+  __syncthreads();
+  if (t < 32) {
+    p.dq1[(long)b * HD + h * 32 + t] = qpart[0][0][t] + qpart[0][1][t] + qpart[0][2][t] + qpart[0][3][t];
+    if (p.dq2) p.dq2[(long)b * HD + h * 32 + t] = qpart[1][0][t] + qpart[1][1][t] + qpart[1][2][t] + qpart[1][3][t];
   }
 }

@@ -592,7 +592,7 @@ int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const f
   p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.kpm = kpm; p.out = out; p.P = P;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
-  STCAT_LAUNCH(attn_q1_fwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  STCAT_LAUNCH(attn_q1_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 
@@ -606,7 +606,7 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
   p.dq1 = dq1; p.dq2 = dq2; p.dk1 = dk1; p.dk2 = dk2; p.dv = dv;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
-  STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(cdiv(B * H, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 
