@@ -472,8 +472,8 @@ int stcat_small_linear_bwd(const float* g, const float* x, const float* w, float
                  M, N, K);
   }
   if (dw) {
-    STCAT_LAUNCH(small_linear_dw_kernel, dim3(grid_for((long)N * K, 256)), dim3(256), 0, (hipStream_t)stream, g, x, dw,
-                 db, M, N, K);
+    STCAT_LAUNCH(small_linear_dw_kernel, dim3(cdiv(K, 32), N), dim3(256), 0, (hipStream_t)stream, g, x, dw, db, M, N,
+                 K);
   }
   return launch_status();
 }
