@@ -202,14 +202,23 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_kernel(AttnBwdParams 
     STCAT_UNROLL
     for (int s = 0; s < 16; ++s)
       dp = STCAT_MFMA_32x32x2(Vs[(kt * 32 + l31) * KLD + hi * 16 + s], dor[s], dp);
+    float pr_[16];  // the 16 stashed probabilities of this tile: issued together, ahead of the dependent MFMA chain
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) pr_[r] = Ptg[(long)(kt * 32 + (r & 3) + 8 * (r >> 2)) * SP];
+    float dw_[16];  // likewise the head-mean-weights gradient (time decoder only)
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key_ = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      dw_[r] = (p.dW && q < p.S && key_ < p.S) ? p.dW[((long)b * p.S + q) * p.S + key_] * invH : 0.f;
+    }
     STCAT_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int krel = kt * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi folded into the base pointers
       const int key = krel + 4 * hi;
       float dpv = dp[r];
-      if (p.dW && q < p.S && key < p.S) dpv += p.dW[((long)b * p.S + q) * p.S + key] * invH;
+      dpv += dw_[r];
       dpv *= stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);  // dP = M' * dP'
-      const float ds = Ptg[(long)krel * SP] * (dpv - delta) * p.scale;
+      const float ds = pr_[r] * (dpv - delta) * p.scale;
       dStg[(long)krel * SP] = ds;
       dq = STCAT_MFMA_32x32x2(ds, Ks[key * 32 + l31], dq);
     }

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stcat_amd import _lib as L, ops
 L.load()
 dev = torch.device("cuda:0")
-B, H, S = 64, 8, int(sys.argv[1]) if len(sys.argv) > 1 else 207
+B, H, S = (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 8, (int(sys.argv[1]) if len(sys.argv) > 1 else 207)
 D = H * 32
 qk = torch.randn(B, S, 2 * D, device=dev, requires_grad=True)
 v = torch.randn(B, S, D, device=dev, requires_grad=True)
