@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(IgemmParams p) {
 // the OIHW weight order), FrozenBN + ReLU epilogue.  Scalar gather (no 16-B alignment on
 // either operand); the frame tensor is read straight from its [T,3,H,W] layout.
 // ---------------------------------------------------------------------------------
+#define STCAT_STEM_KMAX 160  // 3 * 7 * 7 = 147 reduction rows, padded to whole K-tiles of 16
 __global__ void __launch_bounds__(256) igemm_stem_kernel(IgemmParams p) {
   constexpr int BM = 128, BN = 64, BK = 16, LDA = BM + 4, LDBS = BN + 4, TM = 2, TN = 1;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -469,18 +470,29 @@ __global__ void __launch_bounds__(256) igemm_stem_kernel(IgemmParams p) {
   float ra[8], rb[4];
   const int khw = g.KH * g.KW;
   const int nk = (p.K + BK - 1) / BK;
+  // (ci, kh, kw) of a reduction index depend on the index alone: decode all <= 160 of them once per workgroup
+  // (the per-element divisions were ~60 VALU ops each and made the kernel index-math-bound)
+  __shared__ int tdh[STCAT_STEM_KMAX], tdw[STCAT_STEM_KMAX], toff[STCAT_STEM_KMAX];
+  if (t < STCAT_STEM_KMAX) {
+    int dh = 1 << 20, dw_ = 0, off = 0;  // rows past K: forced out of range -> zero fill
+    if (t < p.K) {
+      const int ci = t / khw, rem = t - ci * khw;
+      dh = rem / g.KW;
+      dw_ = rem - dh * g.KW;
+      off = (ci * g.H + dh) * g.W + dw_;
+    }
+    tdh[t] = dh; tdw[t] = dw_; toff[t] = off;
+  }
+  __syncthreads();
+  const long abase = ((long)nb * g.C * g.H + bh) * g.W + bw;  // + toff[r] = ((nb*C + ci)*H + bh + kh)*W + bw + kw
 #define STCAT_STEM_LOAD(KT)                                                              \
   {                                                                                      \
     STCAT_UNROLL                                                                         \
     for (int e = 0; e < 8; ++e) {                                                        \
       const int r = (KT) * BK + ak + e;                                                  \
+      const int h = bh + tdh[r], w = bw + tdw[r];                                        \
       float val = 0.f;                                                                   \
-      if (r < p.K && nb >= 0) {                                                          \
-        const int ci = r / khw, rem = r - ci * khw, kh = rem / g.KW, kw = rem - kh * g.KW; \
-        const int h = bh + kh, w = bw + kw;                                              \
-        if (h >= 0 && h < g.H && w >= 0 && w < g.W)                                      \
-          val = p.A[((long)(nb * g.C + ci) * g.H + h) * g.W + w];                        \
-      }                                                                                  \
+      if (nb >= 0 && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) val = p.A[abase + toff[r]]; \
       ra[e] = val;                                                                       \
     }                                                                                    \
     STCAT_UNROLL                                                                         \
