@@ -278,6 +278,24 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
     }                                                                                                    \
   }
 
+// split-K epilogue: slice 0 also contributes bias and residual; the host zeroes the output and guarantees that no
+// scale / ReLU / mask / second output is requested
+#define STCAT_BS_SPLITK_EPILOGUE_F4(m, n, v4)                                                            \
+  {                                                                                                      \
+    if (blockIdx.z == 0) {                                                                               \
+      if (p.bias) {                                                                                      \
+        const float4 bi = stcat_ld4(p.bias + (n));                                                       \
+        v4.x += bi.x; v4.y += bi.y; v4.z += bi.z; v4.w += bi.w;                                          \
+      }                                                                                                  \
+      if (p.res) {                                                                                       \
+        const float4 rr = stcat_ld4(p.res + (long)(m) * p.ldr + (n));                                    \
+        v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;                                          \
+      }                                                                                                  \
+    }                                                                                                    \
+    float* d_ = p.C + (long)(m) * p.ldc + (n);                                                           \
+    atomicAdd(d_, v4.x); atomicAdd(d_ + 1, v4.y); atomicAdd(d_ + 2, v4.z); atomicAdd(d_ + 3, v4.w);      \
+  }
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -293,7 +311,11 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
   STCAT_UNROLL
   for (int j = 0; j < BN / RP; ++j) b_off[j] = (unsigned)((n0 + trow + RP * j) * p.ldb + (t & 7) * 4) * 4;
   float4 ra[2][BM / RP], rb[2][BN / RP];
-  const int nk = p.K / BK, kend = nk;
+  // optional split of the reduction over grid.z (skinny launches: M <= 64 rows, K >= 1024 — the decoders' FFN):
+  // K-tiles [kbeg, kend) per slice, partial tiles added atomically into the zeroed output
+  const int nk = p.K / BK;
+  const int kbeg = p.k_chunk ? (int)blockIdx.z * p.k_chunk : 0;
+  const int kend = p.k_chunk ? min(nk, kbeg + p.k_chunk) : nk;
 #define STCAT_BSF_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
   {                                                                                                      \
@@ -305,7 +327,7 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
   }
 #define STCAT_BSF_STORE(SET, BUF) \
   STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_R(Bs[BUF], BN, rb[SET])
-  STCAT_BS_PIPELINE(STCAT_BSF_LOAD, STCAT_BSF_STORE)
+  STCAT_BS_PIPELINE_RANGE(STCAT_BSF_LOAD, STCAT_BSF_STORE, kbeg, kend)
 #undef STCAT_BSF_LOAD
 #undef STCAT_BSF_STORE
   STCAT_BS_ACC_TO_LDS
@@ -316,7 +338,11 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
     const int m = m0 + row, n = n0 + c4 * 4;
     if (m < p.M) {
       float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
-      STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)
+      if (p.k_chunk) {
+        STCAT_BS_SPLITK_EPILOGUE_F4(m, n, v4)
+      } else {
+        STCAT_BS_FWD_EPILOGUE_F4(m, n, v4)
+      }
     }
   }
 }
@@ -438,7 +464,9 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
       b_off[j][e] = i < BN * 2 ? (unsigned)((kgrp * 4 + e) * p.ldb + n0 + rowgrp * 4) * 4 : STCAT_BUF_OOB;
   }
   float4 ra[2][BM / 32], rb[2][JB][4];
-  const int nk = p.K / BK, kend = nk;
+  const int nk = p.K / BK;
+  const int kbeg = p.k_chunk ? (int)blockIdx.z * p.k_chunk : 0;   // optional split-K, as in the forward kernel
+  const int kend = p.k_chunk ? min(nk, kbeg + p.k_chunk) : nk;
 #define STCAT_BSD_LOAD(KT, SET)                                                                          \
   STCAT_BS_LOAD_A_GATHER(KT, BM, SET)                                                                    \
   {                                                                                                      \
@@ -453,7 +481,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
   }
 #define STCAT_BSD_STORE(SET, BUF) \
   STCAT_BS_STORE_R(As[BUF], BM, ra[SET]) STCAT_BS_STORE_O(Bs[BUF], BN, rb[SET])
-  STCAT_BS_PIPELINE(STCAT_BSD_LOAD, STCAT_BSD_STORE)
+  STCAT_BS_PIPELINE_RANGE(STCAT_BSD_LOAD, STCAT_BSD_STORE, kbeg, kend)
 #undef STCAT_BSD_LOAD
 #undef STCAT_BSD_STORE
   STCAT_BS_ACC_TO_LDS
@@ -464,6 +492,10 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
     const int m = m0 + row, n = n0 + c4 * 4;
     if (m < p.M) {
       float4 v4 = stcat_ld4(&Cs[row * LDC + c4 * 4]);
+      if (p.k_chunk) {
+        STCAT_BS_SPLITK_EPILOGUE_F4(m, n, v4)
+        continue;
+      }
       if (p.res) {
         const float4 rr = stcat_ld4(p.res + (long)m * p.ldr + n);
         v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;

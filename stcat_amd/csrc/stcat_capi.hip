@@ -143,7 +143,34 @@ static bool sk_wanted(const IgemmParams& p, int workers) {
   return g_streamk > 0;
 }
 
+// Skinny launches with a long reduction (the decoders' FFN on [T,256] states: M <= 64, K = 2048): 4 workgroups
+// walking 64 K-tiles each is ~35 us of pure latency; split the reduction over grid.z into >= 8-tile slices that
+// add into the zeroed output.  Only when the epilogue is bias / residual (no scale, ReLU, mask, second output).
+static int skinny_splits(const IgemmParams& p) {
+  if (!(bs_ok(p) && p.M <= 64 && p.K >= 1024 && !p.scale && !p.relu && !p.mask && !p.C2 && p.c_group >= p.M)) return 0;
+  const int nk = p.K / 32;
+  int splits = nk / 8;
+  if (splits > 8) splits = 8;
+  return splits >= 2 ? splits : 0;
+}
+static int skinny_zero(const IgemmParams& p, hipStream_t st) {
+  for (int m = 0; m < (p.ldc == p.N ? 1 : p.M); ++m) {  // dense output: one memset, else row by row
+    const size_t bytes = (p.ldc == p.N ? (size_t)p.M * p.N : (size_t)p.N) * sizeof(float);
+    if (hipMemsetAsync(p.C + (size_t)m * p.ldc, 0, bytes, st) != hipSuccess) return fail("split-K: memset failed");
+  }
+  return 0;
+}
+
 int launch_fwd(const IgemmParams& p, hipStream_t st) {
+  if (const int splits = skinny_splits(p)) {
+    IgemmParams q = p;
+    q.k_chunk = cdiv(p.K / 32, splits);
+    if (int rc = skinny_zero(p, st)) return rc;
+    const dim3 grid(cdiv(p.M, 64) * (p.N / 64), 1, cdiv(p.K / 32, q.k_chunk));
+    if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_fwd_kernel<64, 64, 3>), grid, dim3(256), 0, st, q); }
+    else { STCAT_LAUNCH((igemm_bs_fwd_kernel<64, 64, 2>), grid, dim3(256), 0, st, q); }
+    return launch_status();
+  }
   {
     float* ws = nullptr;
     int workers = 0;
@@ -191,6 +218,15 @@ int launch_fwd(const IgemmParams& p, hipStream_t st) {
 }
 
 int launch_dgrad(const IgemmParams& p, hipStream_t st) {
+  if (const int splits = skinny_splits(p)) {
+    IgemmParams q = p;
+    q.k_chunk = cdiv(p.K / 32, splits);
+    if (int rc = skinny_zero(p, st)) return rc;
+    const dim3 grid(cdiv(p.M, 64) * (p.N / 64), 1, cdiv(p.K / 32, q.k_chunk));
+    if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_dgrad_kernel<64, 64, 3>), grid, dim3(256), 0, st, q); }
+    else { STCAT_LAUNCH((igemm_bs_dgrad_kernel<64, 64, 2>), grid, dim3(256), 0, st, q); }
+    return launch_status();
+  }
   int BM, BN;
   pick_tile(p.M, p.N, BM, BN);
   if (BM == 256) BM = 128;

@@ -548,6 +548,10 @@ def _gemm_bf16x3(dev, big):
         _conv_case(dev, 2, 6, 7, 128, 256, 1, 1, 0, relu=True, res=False, tile=(256, 128))
         _conv_case(dev, 1, 5, 6, 128, 256, 3, 1, 1, relu=False, res=True, tile=(256, 128))
         _linear_case(dev, 100, 256, 128, relu=False, res=False, tile=(256, 128))
+        # skinny long-reduction launches (decoder FFN): split-K over grid.z with an atomic epilogue — forward with
+        # bias + residual (K = 2048) and the data gradient of a 256 -> 2048 layer (reduction over N = 2048)
+        _linear_case(dev, 64, 256, 2048, relu=False, res=True)
+        _linear_case(dev, 37, 2048, 256, relu=True, res=False)
         # stream-K scheduling of the forward GEMM (equal shares of tiles x K-steps per workgroup, split tiles
         # finished by the fix-up kernel): tile tails, whole tiles and tile heads; also the data gradient through it
         L.call("stcat_debug_streamk", 1)
