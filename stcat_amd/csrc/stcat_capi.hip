@@ -143,11 +143,11 @@ static bool sk_wanted(const IgemmParams& p, int workers) {
   return g_streamk > 0;
 }
 
-// Skinny launches with a long reduction (the decoders' FFN on [T,256] states: M <= 64, K = 2048): 4 workgroups
+// Skinny launches with a long reduction (FFN of the decoders / temporal encoder on [T(+1),256] states, K = 2048): 4-8 workgroups
 // walking 64 K-tiles each is ~35 us of pure latency; split the reduction over grid.z into >= 8-tile slices that
 // add into the zeroed output.  Only when the epilogue is bias / residual (no scale, ReLU, mask, second output).
 static int skinny_splits(const IgemmParams& p) {
-  if (!(bs_ok(p) && p.M <= 64 && p.K >= 1024 && !p.scale && !p.relu && !p.mask && !p.C2 && p.c_group >= p.M)) return 0;
+  if (!(bs_ok(p) && p.M <= 128 && p.K >= 1024 && !p.scale && !p.relu && !p.mask && !p.C2 && p.c_group >= p.M)) return 0;
   const int nk = p.K / 32;
   int splits = nk / 8;
   if (splits > 8) splits = 8;

@@ -551,6 +551,7 @@ def _gemm_bf16x3(dev, big):
         # skinny long-reduction launches (decoder FFN): split-K over grid.z with an atomic epilogue — forward with
         # bias + residual (K = 2048) and the data gradient of a 256 -> 2048 layer (reduction over N = 2048)
         _linear_case(dev, 64, 256, 2048, relu=False, res=True)
+        _linear_case(dev, 65, 256, 1024, relu=False, res=True)        # T+1 rows: two row tiles
         _linear_case(dev, 37, 2048, 256, relu=True, res=False)
         # stream-K scheduling of the forward GEMM (equal shares of tiles x K-steps per workgroup, split tiles
         # finished by the fix-up kernel): tile tails, whole tiles and tile heads; also the data gradient through it
