@@ -537,7 +537,8 @@ int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const
                         float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (D != 256) return fail("layernorm: D must be 256 (got %d)", D);
   if (drop_p > 0.f && !dx) return fail("layernorm_bwd: dropout needs the dx output");
-  STCAT_LAUNCH(layernorm_bwd_kernel, dim3(grid_for(M, 16, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, res, gamma,
+  // small M (the decoders' [T,256] states): one row per wave, so the rows of a launch are normalised in parallel
+  STCAT_LAUNCH(layernorm_bwd_kernel, dim3(grid_for(M, M <= 1024 ? 4 : 16, 512)), dim3(256), 0, (hipStream_t)stream, dy, x, res, gamma,
                mean, rstd, dz, dx, dgamma, dbeta, M, stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base));
   return launch_status();
 }
@@ -601,8 +602,8 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   const int nt = cdiv(S, 32);
   if (dw) {
-    STCAT_LAUNCH(attn_dw_corr_kernel, dim3(grid_for((long)B * H * S, 256)), dim3(256), 0, (hipStream_t)stream, pt, dw,
-                 corr, B, H, S, nt * 32, p.drop);
+    STCAT_LAUNCH(attn_dw_corr_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, pt, dw, corr, B, H, S, nt * 32,
+                 p.drop);
   }
   STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_bwd_dq_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
   int rc = launch_status();
