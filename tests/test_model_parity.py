@@ -195,10 +195,13 @@ def _check_train_mode(dev):
     o1, l1, g1 = _train_step(dev, seed=11)
     o2, l2, g2 = _train_step(dev, seed=11)
     o3, l3, _ = _train_step(dev, seed=12)
-    # same seed -> the same masks in forward AND backward (bitwise, up to the atomics of the split-K weight gradients)
+    # same seed -> the same masks in forward AND backward.  Not bitwise on the GPU: the split-K launches (weight
+    # gradients, the skinny FFN forward) add partial sums atomically in arrival order — compare to fp32 round-off;
+    # a different mask would move the outputs by O(1).
     for k in o1:
-        assert torch.equal(o1[k], o2[k]), k
-    assert l1 == l2
+        close(o2[k], o1[k], 1e-5, "replayed output " + k)
+        assert torch.equal(o1[k] == 0, o2[k] == 0), k      # the dropped positions themselves are identical
+    assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1))
     for n in g1:
         close(g2[n], g1[n], 1e-5, "replayed gradient " + n)
     assert all(torch.isfinite(v).all() for v in g1.values()) and math.isfinite(l1)
