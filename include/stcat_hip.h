@@ -65,6 +65,11 @@ int stcat_conv_dgrad(const float* g, const float* w, const float* add, const flo
 /* wt = stcat_weight_transpose(w): OHWI [Cout][taps][Cin] -> [taps][Cin][Cout].  When given (and a split-bf16 mode is
  * active) the data gradient runs on the forward kernel's staging path; NULL keeps the generic path. */
 int stcat_weight_transpose(const float* w, float* wt, int Cout, int taps, int Cin, void* stream);
+/* the same transpose for many weights in ONE launch: DEVICE table of entries
+ *   { const float* w; float* wt; int Cout, taps, Cin; int blk0, nbx, nby; }   (stcat_weight_transpose_entry_bytes() == 40)
+ * where entry e owns grid blocks [blk0, blk0 + nbx*nby*taps), nbx = ceil(Cin/32), nby = ceil(Cout/32), blk0 ascending */
+int stcat_weight_transpose_entry_bytes(void);
+int stcat_weight_transpose_multi(const void* table, int n_entries, int total_blocks, void* stream);
 /* dw (OHWI, caller-zeroed) += sum over pixels g (x) gathered x  (autograd of conv2d w.r.t. weight) */
 int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, int W, int Cin, int Cout, int KH,
                      int KW, int stride, int pad, void* stream);

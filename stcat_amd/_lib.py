@@ -25,6 +25,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_conv_fwd": "ppppppiiiiiiiiiis",
     "stcat_conv_dgrad": "pppppppppiiiiiiiiis",
     "stcat_weight_transpose": "ppiiis",
+    "stcat_weight_transpose_multi": "piis",
+    "stcat_weight_transpose_entry_bytes": "",
     "stcat_conv_wgrad": "pppiiiiiiiiis",
     "stcat_act_bwd": "ppppplii" + "s",
     "stcat_pos_sine_2d": "pppiiis",

@@ -72,6 +72,7 @@ class ResNet101Body(nn.Module):
 
     def __init__(self):
         super().__init__()
+        self._wt_cache = ops.WeightTransposer()  # transposed conv weights for the data-gradient GEMMs (backward)
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(64)
         inplanes = 64
@@ -134,6 +135,12 @@ class _BackboneFn(Function):
     def backward(ctx, dy):
         grads = {}
         tape = ctx.tape
+        # transposed weights for every data-gradient GEMM of this pass: one launch (ops.WeightTransposer)
+        wts = {}
+        if ops.L.get_mma_mode() != "f32":
+            ws = [w for rec in tape for w in rec[5] if w is not None]
+            wts = ctx.body._wt_cache.refresh(ws)
+        _wt = lambda w: wts.get(w.data_ptr())  # noqa: E731
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
         # top of the stack: dz = dy * [y > 0] (identity-path gradient), g3 = dz * scale3 (conv3 upstream)
         g3, dz = ops.act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
@@ -142,9 +149,9 @@ class _BackboneFn(Function):
             need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
             grads[id(blk.conv3.weight)] = ops.conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
             # each dgrad epilogue applies the ReLU+BN backward of the layer below (no intermediate dO tensor)
-            g2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0, mask_y=o2, mask_scale=s2)
+            g2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0, mask_y=o2, mask_scale=s2, wt=_wt(w3))
             grads[id(blk.conv2.weight)] = ops.conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
-            g1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1, mask_y=o1, mask_scale=s1)
+            g1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1, mask_y=o1, mask_scale=s1, wt=_wt(w2))
             grads[id(blk.conv1.weight)] = ops.conv_wgrad_raw(g1, x, w1.shape, 1, 0)
             gd = None
             if wd is not None:
@@ -155,10 +162,10 @@ class _BackboneFn(Function):
             # block boundary: x is the ReLU output of the block below; its dz / g3 come out of this epilogue
             s3_below = tape[idx - 1][6][2]
             if wd is not None:
-                part = ops.conv_dgrad_raw(gd, wd, x.shape, blk.stride, 0)
-                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=part, out=part, mask_y=x, scale2=s3_below)
+                part = ops.conv_dgrad_raw(gd, wd, x.shape, blk.stride, 0, wt=_wt(wd))
+                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=part, out=part, mask_y=x, scale2=s3_below, wt=_wt(w1))
             else:
-                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dz, mask_y=x, scale2=s3_below)
+                dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dz, mask_y=x, scale2=s3_below, wt=_wt(w1))
         out = []
         for w in ctx.body.parameters():  # same order as the *weights passed to forward
             g = grads.get(id(w))

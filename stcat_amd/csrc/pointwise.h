@@ -418,3 +418,35 @@ __global__ void dropout_kernel(const float* x, const float* res, float* y, long 
     }
   }
 }
+
+// The same transpose for MANY weights in one launch (every conv of a backward pass): entry e owns blocks
+// [blk0, blk0 + nbx*nby*taps) of the grid; a block finds its entry by binary search in the device table.
+struct WtEntry {
+  const float* w;
+  float* wt;
+  int Cout, taps, Cin;
+  int blk0, nbx, nby;
+};
+__global__ void __launch_bounds__(256) weight_transpose_multi_kernel(const WtEntry* tab, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last entry with blk0 <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WtEntry e = tab[lo];
+  const int rel = blockIdx.x - e.blk0;
+  const int bx = rel % e.nbx, by = (rel / e.nbx) % e.nby, tap = rel / (e.nbx * e.nby);
+  const int ci0 = bx * 32, co0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < e.Cout && ci < e.Cin) ? e.w[((long)co * e.taps + tap) * e.Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < e.Cin && co < e.Cout) e.wt[((long)tap * e.Cin + ci) * e.Cout + co] = tile[tx][r];
+  }
+}
+

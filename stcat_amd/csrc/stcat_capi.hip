@@ -407,6 +407,15 @@ int stcat_weight_transpose(const float* w, float* wt, int Cout, int taps, int Ci
   return launch_status();
 }
 
+int stcat_weight_transpose_entry_bytes(void) { return (int)sizeof(WtEntry); }
+
+int stcat_weight_transpose_multi(const void* table, int n_entries, int total_blocks, void* stream) {
+  if (n_entries <= 0 || total_blocks <= 0) return fail("weight_transpose_multi: empty table");
+  STCAT_LAUNCH(weight_transpose_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+               (const WtEntry*)table, n_entries);
+  return launch_status();
+}
+
 int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G, float* dres, long n, int C,
                   int relu, void* stream) {
   if (n % 4 != 0 || C % 4 != 0) return fail("act_bwd: n and C must be multiples of 4");

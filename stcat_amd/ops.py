@@ -772,15 +772,51 @@ def conv_fwd_raw(x, w_ohwi, scale, bias, res, stride, pad, relu):
     return y
 
 
+class WeightTransposer:
+    """Transposed copies W[Cout,taps,Cin] -> [taps,Cin,Cout] of a fixed list of conv weights, refreshed with ONE
+    launch per step (stcat_weight_transpose_multi) instead of one ~5 us launch per layer.  The transposed buffers
+    and the device table are persistent; the table is rebuilt only if a weight moved."""
+
+    def __init__(self):
+        self.key = None
+        self.table = None
+        self.wts = {}
+        self.total = 0
+
+    def refresh(self, weights):
+        """weights: list of OHWI tensors [Cout,KH,KW,Cin]; returns {weight.data_ptr(): transposed tensor}"""
+        import numpy as np
+        key = tuple(w.data_ptr() for w in weights)
+        if key != self.key:
+            dt = np.dtype([("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
+                           ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4")])
+            assert dt.itemsize == L.load().stcat_weight_transpose_entry_bytes()
+            tab = np.zeros(len(weights), dtype=dt)
+            self.wts, blk = {}, 0
+            for i, w in enumerate(weights):
+                Cout, KH, KW, Cin = w.shape
+                taps = KH * KW
+                wt = torch.empty(taps, Cin, Cout, device=w.device, dtype=_f32)
+                self.wts[w.data_ptr()] = wt
+                nbx, nby = (Cin + 31) // 32, (Cout + 31) // 32
+                tab[i] = (w.data_ptr(), wt.data_ptr(), Cout, taps, Cin, blk, nbx, nby)
+                blk += nbx * nby * taps
+            self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(weights[0].device)
+            self.total, self.key, self.n = blk, key, len(weights)
+        L.call("stcat_weight_transpose_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
+        return self.wts
+
+
 def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None, mask_y=None, mask_scale=None,
-                   scale2=None):
+                   scale2=None, wt=None):
     """mask_y / mask_scale: fuse the ReLU+FrozenBN backward of the layer that produced this conv's input.
     scale2: also return dx * scale2[c] as a second tensor (block-boundary form)."""
     n, H, W, Cin = in_shape
     Cout, KH, KW, _ = w_ohwi.shape
     dx = _empty(g, n, H, W, Cin) if out is None else out
     dx2 = _empty(g, n, H, W, Cin) if scale2 is not None else None
-    wt = weight_transpose(w_ohwi.view(Cout, KH * KW, Cin)) if L.get_mma_mode() != "f32" else None
+    if wt is None and L.get_mma_mode() != "f32":
+        wt = weight_transpose(w_ohwi.view(Cout, KH * KW, Cin))
     L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), L._ptr(mask_y), L._ptr(mask_scale),
            dx.data_ptr(), L._ptr(dx2), L._ptr(scale2), L._ptr(wt), n, H, W, Cin, Cout, KH, KW, stride, pad,
            L.stream_of(g))
