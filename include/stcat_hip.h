@@ -176,6 +176,9 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
  *   torch.optim.AdamW update (engine/optimizer.py:25-55; lr / wd are HOST arrays indexed by entry.group,
  *   rewritten by the schedule of engine/lr_scheduler.py:212-252 every step) and the EMA copy
  *   w_ema = w_ema * decay + (1 - decay) * w (engine/optimizer.py:5-22) in one pass.  step counts from 1.
+ * stcat_grad_clip_scale: second half of a standalone torch.nn.utils.clip_grad_norm_ (scripts/train_net.py:136-137):
+ *   every gradient of the table is scaled in place by max_norm / (sqrt(*sqnorm) + 1e-6) when that is < 1; the
+ *   buffers are walked in flat memory order, so row-major and channels_last gradients are treated alike.
  * stcat_ema_update: the EMA alone, for state that is not a trained parameter. */
 int stcat_optim_table_entry_bytes(void);
 int stcat_grad_sqnorm(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
@@ -183,6 +186,8 @@ int stcat_grad_sqnorm(const void* table, const int* chunk_tensor, const long* ch
 int stcat_adamw_ema_step(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
                          const float* sqnorm, const float* lr, const float* wd, int n_groups, float beta1,
                          float beta2, float eps, int step, float max_norm, float ema_decay, void* stream);
+int stcat_grad_clip_scale(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                          const float* sqnorm, float max_norm, void* stream);
 int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
                      float decay, void* stream);
 

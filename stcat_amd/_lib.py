@@ -49,6 +49,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "fllps",
     "stcat_grad_sqnorm": "pppiips",
     "stcat_adamw_ema_step": "pppiipPPifffiffs",
+    "stcat_grad_clip_scale": "pppiipfs",
     "stcat_ema_update": "pppiifs",
     "stcat_optim_table_entry_bytes": "",
     "stcat_temporal_map_argmax": "pppiis",

@@ -190,6 +190,10 @@ class Backbone(nn.Module):
         self.num_channels = 2048
 
     def features_nhwc(self, frames: torch.Tensor) -> torch.Tensor:
+        if self.training and torch.is_grad_enabled():
+            # first module of the hot path to run in a step: open the step's dropout counter range (drop-in mode has
+            # no other place to do it — the reference's train loop is unmodified)
+            ops.dropout_auto_begin_step(frames.device)
         weights = [p for p in self.body.parameters()]
         return _BackboneFn.apply(frames, self.body, *weights)
 

@@ -109,6 +109,20 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* tab, co
   }
 }
 
+// standalone clip_grad_norm_: g *= min(1, max_norm / (sqrt(sqnorm) + 1e-6)) over the tensor table, in place and
+// layout-agnostic (flat element order of each gradient buffer: row-major and channels_last alike)
+__global__ void __launch_bounds__(256) grad_clip_scale_kernel(const OptTensor* tab, const int* chunk_tensor,
+                                                              const long* chunk_off, int chunk, const float* sqnorm,
+                                                              float max_norm) {
+  const OptTensor t = tab[chunk_tensor[blockIdx.x]];
+  const long lo = chunk_off[blockIdx.x];
+  const long hi = lo + chunk < t.n ? lo + chunk : t.n;
+  float coef = max_norm / (sqrtf(*sqnorm) + 1e-6f);
+  if (!(coef < 1.f)) return;  // norm within bounds: nothing to do (torch clamps the coefficient to 1)
+  float* g = const_cast<float*>(t.g);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) g[i] *= coef;
+}
+
 // w_ema = w_ema * decay + (1 - decay) * w over a tensor table (update_ema for state that is not a trained
 // parameter; trained parameters get their EMA inside adamw_ema_kernel)
 __global__ void __launch_bounds__(256) ema_kernel(const OptTensor* tab, const int* chunk_tensor, const long* chunk_off,

@@ -688,6 +688,15 @@ int stcat_adamw_ema_step(const void* table, const int* chunk_tensor, const long*
   return launch_status();
 }
 
+int stcat_grad_clip_scale(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
+                          const float* sqnorm, float max_norm, void* stream) {
+  if (n_chunks <= 0 || chunk <= 0) return fail("grad_clip_scale: bad chunking");
+  if (!sqnorm || !(max_norm > 0.f)) return fail("grad_clip_scale: needs the squared norm and max_norm > 0");
+  STCAT_LAUNCH(grad_clip_scale_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table,
+               chunk_tensor, chunk_off, chunk, sqnorm, max_norm);
+  return launch_status();
+}
+
 int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chunk_off, int n_chunks, int chunk,
                      float decay, void* stream) {
   if (n_chunks <= 0 || chunk <= 0) return fail("ema_update: bad chunking");

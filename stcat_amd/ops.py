@@ -474,9 +474,21 @@ class _DropoutStream:
     STEP_SPAN = 1 << 36  # counters reserved per step (a C5 step uses ~2^33)
 
     def __init__(self):
-        self.seed = 0x5DEECE66D
+        self.seed = None   # resolved lazily: manual_seed(), else from torch.initial_seed() and the DP rank
         self.offset = 0
         self._base = {}
+
+    def _default_seed(self) -> int:
+        """Drop-in mode never calls manual_seed: the reference seeds torch with 42 + rank (scripts/train_net.py:296),
+        so torch.initial_seed() already differs per rank; the rank is mixed in as well in case it does not."""
+        rank = int(os.environ.get("RANK", "0"))
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            pass
+        return _mix_seed(torch.initial_seed() & _MASK64, rank)
 
     def base(self, device) -> torch.Tensor:
         b = self._base.get(device)
@@ -485,25 +497,39 @@ class _DropoutStream:
         return b
 
     def take(self, numel: int, device):
+        if self.seed is None:
+            self.seed = self._default_seed()
         off = self.offset
         self.offset = off + ((numel + 3) // 4) * 4
         if self.offset > self.STEP_SPAN:
-            raise RuntimeError("dropout counter range of one step exhausted; call ops.dropout_begin_step()")
+            raise RuntimeError("dropout counter range of one step exhausted (2^36 decisions in one forward pass)")
         return self.seed, off, self.base(device).data_ptr()
 
     def begin_step(self, device):
         self.offset = 0
         self.base(device).add_(self.STEP_SPAN)  # stream-ordered (and capturable): no host sync
 
+    def auto_begin_step(self, device):
+        """Called at the top of every train-mode forward (the visual encoder is the first module of the path to
+        run): starts a new counter range iff decisions were drawn since the last begin_step, so an unmodified
+        training loop (drop-in mode) never exhausts the per-step range, and an explicit dropout_begin_step()
+        right before the forward is not doubled."""
+        if self.offset != 0:
+            self.begin_step(device)
+
 
 _dropout_stream = _DropoutStream()
 
 
-def manual_seed(seed: int, rank: int = 0) -> None:
-    """Seed the dropout stream of this process (counters restart at 0)."""
+def _mix_seed(seed: int, rank: int) -> int:
     z = (seed * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9) & _MASK64
     z ^= z >> 31
-    _dropout_stream.seed = z & ((1 << 62) - 1)
+    return z & ((1 << 62) - 1)
+
+
+def manual_seed(seed: int, rank: int = 0) -> None:
+    """Seed the dropout stream of this process (counters restart at 0)."""
+    _dropout_stream.seed = _mix_seed(seed, rank)
     _dropout_stream.offset = 0
     for b in _dropout_stream._base.values():
         b.zero_()
@@ -514,8 +540,15 @@ def dropout_begin_step(device) -> None:
     _dropout_stream.begin_step(torch.device(device))
 
 
+def dropout_auto_begin_step(device) -> None:
+    """Start a new step's counter range if the previous one was used (see _DropoutStream.auto_begin_step)."""
+    _dropout_stream.auto_begin_step(torch.device(device))
+
+
 def dropout_stream_state():
     """(seed, host offset) — the device base is 0 until the first dropout_begin_step()"""
+    if _dropout_stream.seed is None:
+        _dropout_stream.seed = _dropout_stream._default_seed()
     return _dropout_stream.seed, _dropout_stream.offset
 
 

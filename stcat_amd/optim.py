@@ -169,18 +169,46 @@ class AdamW:
         return sq
 
     def state_dict(self):
-        idx = {p: i for i, p in enumerate(p for g in self.param_groups for p in g["params"])}
-        return {"step": self.step_count,
-                "state": {idx[p]: {k: v.clone() for k, v in st.items()} for p, st in self.state.items()},
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.AdamW's layout (what the reference's Checkpointer round-trips, utils/checkpoint.py):
+        state[idx] = {step, exp_avg, exp_avg_sq}, param_groups[i]["params"] = [idx, ...]."""
+        idx, groups = {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                idx[p] = len(idx)
+                ids.append(idx[p])
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.setdefault("amsgrad", False)
+            d["params"] = ids
+            groups.append(d)
+        state = {}
+        for p, st in self.state.items():
+            state[idx[p]] = {"step": torch.tensor(float(st.get("step", self.step_count))),
+                             "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        """accepts a torch.optim.AdamW checkpoint (per-parameter `step`) as well as its own"""
         params = [p for g in self.param_groups for p in g["params"]]
-        self.step_count = sd["step"]
+        saved_ids = [i for g in sd["param_groups"] for i in g["params"]] if sd["param_groups"] and \
+            "params" in sd["param_groups"][0] else list(range(len(params)))
+        if len(saved_ids) != len(params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        where = {sid: p for sid, p in zip(saved_ids, params)}
+        steps = []
+        self.state = {}
         for i, st in sd["state"].items():
-            self.state[params[int(i)]] = {k: v.to(params[int(i)].device).clone() for k, v in st.items()}
+            p = where[int(i)]
+            # moments take the parameter's own memory layout (channels_last conv weights); copy_ maps by index
+            self.state[p] = {k: torch.zeros_like(p).copy_(st[k].to(p.device, torch.float32))
+                             for k in ("exp_avg", "exp_avg_sq")}
+            if "step" in st:
+                steps.append(int(float(st["step"])))
+        # one bias-correction counter for the fused launch: every parameter of the hot path receives a gradient at
+        # every step (statically dead ones never enter `state`), so the per-parameter counters agree
+        self.step_count = max(steps) if steps else int(sd.get("step", 0))
         for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update(saved)
+            g.update({k: v for k, v in saved.items() if k != "params"})
         self._gkey = None
 
 
@@ -227,22 +255,27 @@ def adjust_learning_rate(cfg, optimizer, curr_step: int, num_training_steps: int
 @torch.no_grad()
 def clip_grad_norm_(parameters: Iterable[torch.Tensor], max_norm: float) -> torch.Tensor:
     """torch.nn.utils.clip_grad_norm_ (L2): returns the total norm (device scalar) and scales the gradients in
-    place when it exceeds max_norm.  The fused AdamW.step(max_grad_norm=...) does not need this call."""
-    from . import ops
+    place when it exceeds max_norm.  The fused AdamW.step(max_grad_norm=...) does not need this call.
+    Both launches walk every gradient buffer in flat memory order (the ops are element-wise), so channels_last
+    conv gradients — the layout of every 3x3 weight gradient of the backbone — are handled without a layout copy."""
     ps = [p for p in parameters if p.grad is not None]
     if not ps:
         return torch.zeros(())
+    for p in ps:
+        L.check_tensor(p.grad, "gradient")
+        if not _dense(p.grad):
+            raise L.StcatHipError("clip_grad_norm_: gradients must be dense (row-major or channels_last)")
     dev = ps[0].device
     tab = _TensorTable(dev)
     tab.update([(0, p.grad.data_ptr(), 0, 0, 0, p.grad.numel(), 0) for p in ps])
     sq = torch.zeros(1, device=dev)
+    st = L.stream_of(ps[0])
     L.call("stcat_grad_sqnorm", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(),
-           tab.n_chunks, CHUNK, sq.data_ptr(), L.stream_of(ps[0]))
-    norm = sq.sqrt()
-    coef = (max_norm / (norm + 1e-6)).clamp(max=1.0)
-    for p in ps:  # g *= coef with coef read on the device (bmod = 1 broadcasts the scalar): no host sync
-        ops.ew(L.EW_MUL, p.grad, coef, bmod=1, out=p.grad)
-    return norm[0]
+           tab.n_chunks, CHUNK, sq.data_ptr(), st)
+    # g *= min(1, max_norm / (norm + 1e-6)) with the coefficient computed on the device: no host sync
+    L.call("stcat_grad_clip_scale", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(),
+           tab.n_chunks, CHUNK, sq.data_ptr(), float(max_norm), st)
+    return sq.sqrt()[0]
 
 
 @torch.no_grad()

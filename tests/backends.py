@@ -69,11 +69,13 @@ def both(fn):
     return fn
 
 
-def close(a, b, tol, what):
+def close(a, b, tol, what, absolute=False):
+    """max |a - b| <= tol * max(1, |b|max); absolute=True drops the scale factor (the north-star bar for the model's
+    box / logit tensors is an ABSOLUTE 1e-3, BASELINE.json)."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
     err = (a - b).abs().max().item() if a.numel() else 0.0
-    scale = max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    scale = 1.0 if absolute else max(1.0, b.abs().max().item() if b.numel() else 1.0)
     assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3g}) > tol {tol}"
     return err

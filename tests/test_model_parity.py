@@ -21,6 +21,7 @@ from tests.backends import close, use_emu, use_hip
 
 OUT_TOL = 1e-3
 GRAD_TOL = 1e-3
+BENCH_MMA = "bf16x3"   # the arithmetic bench.py measures by default
 GRAD_ABS_FLOOR = 2e-6
 
 
@@ -93,15 +94,42 @@ def _run_oracle_impl(T, res, L, with_backward, dtype):
     return out, boxes, sted, losses, grads
 
 
-def _compare(hip, ref, with_backward=True, g64=None, grad_slack=1.0):
-    """grad_slack scales the gradient tolerances (outputs/spans/losses always use the north-star bars):
-    1 for fp32-class arithmetic, 20 for bf16x3 whose 2^-16 product noise flips ~100x more ReLU kinks."""
+def _family(name: str) -> str:
+    for k in ("layer2", "layer3", "layer4"):
+        if k in name:
+            return "backbone." + k
+    for k in ("input_proj", "ground_encoder", "ground_decoder.temp_decoder", "ground_decoder.decoder",
+              "ground_decoder.template_generator", "temp_embed", "action_embed", "bbox_embed"):
+        if name.startswith(k):
+            return k
+    return "other"
+
+
+# Per-family caps on the rel-L2 distance of EVERY gradient tensor from exact (fp64) arithmetic in the 16-bit-operand
+# modes (bf16x3 and its plane-format form): operands carry 16 significand bits (hi + lo bf16 pieces), so a product
+# is good to ~2^-16 where fp32 gives 2^-24.  MEASURED on the GPU (tools/grad_error_report.py, profiles/r02_grad_error_*.json):
+# worst tensor per family at C3 (T=64, 448^2) / C1 (T=8, 224^2) — layer2 7.6e-3 / 8.2e-3, layer3 4.2e-3 / 7.9e-3,
+# layer4 1.9e-3 / 1.7e-3, encoder 9.3e-4 / 5.0e-4, time decoder 3.4e-3 / 1.6e-3 — against 1.3e-3 / 1.7e-3 (layer2)
+# for the exact-fp32 mode and 1.6e-3 / 1.3e-2 for the fp32 CPU reference itself.  Caps = measured x ~1.5, none above
+# 1.2e-2 (VERDICT r01 item 1b asks for <= 1e-2-class bounds instead of the former 20x slack = 0.2).
+GRAD_CAPS_16BIT = {
+    "backbone.layer2": 1.2e-2, "backbone.layer3": 1.2e-2, "backbone.layer4": 4e-3, "input_proj": 2e-3,
+    "ground_encoder": 2e-3, "ground_decoder.temp_decoder": 6e-3, "ground_decoder.decoder": 6e-3,
+    "ground_decoder.template_generator": 2e-3, "temp_embed": 2e-3, "action_embed": 2e-3, "bbox_embed": 2e-3,
+    "other": 2e-3,
+}
+
+
+def _compare(hip, ref, with_backward=True, g64=None, grad_slack=1.0, grad_caps=None):
+    """Outputs / spans / losses always use the north-star bars.  Gradients: fp32-class modes (f32, bf16x6) must be
+    as close to exact arithmetic as the fp32 CPU reference is (calibrated bound below, grad_slack = 1); the
+    16-bit-operand modes pass `grad_caps` = per-family caps on every tensor's rel-L2 error."""
     keep, losses, grads = hip
     out, boxes, sted, rlosses, rgrads = ref
     for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights"):
-        close(keep[k], out[k], OUT_TOL, k)
+        close(keep[k], out[k], OUT_TOL, k, absolute=True)       # "box/logit tensors within 1e-3": absolute
         for i, aux in enumerate(keep["aux"]):
-            close(aux[k], out["aux_outputs"][i][k], OUT_TOL, f"aux{i}/{k}")
+            close(aux[k], out["aux_outputs"][i][k], OUT_TOL, f"aux{i}/{k}", absolute=True)
     close(keep["post_boxes"], boxes, OUT_TOL, "post boxes")
     assert keep["post_sted"] == [sted], (keep["post_sted"], sted)  # bit-exact span
     if not with_backward:
@@ -137,6 +165,19 @@ def _compare(hip, ref, with_backward=True, g64=None, grad_slack=1.0):
         e_ref = (b - exact).norm().item() / (exact.norm().item() + floor)
         gross = (a - exact).abs().max().item() / (exact.abs().max().item() + GRAD_ABS_FLOOR / GRAD_TOL)
         report.append((e_hip / (3 * e_ref + GRAD_TOL * grad_slack), e_hip, e_ref, gross, name))
+    if grad_caps is not None:
+        over = [(h / grad_caps[_family(n)], h, r, g, n) for _, h, r, g, n in report if h > grad_caps[_family(n)]]
+        over.sort(reverse=True)
+        assert not missing, f"parameters without a HIP gradient: {missing[:8]}"
+        assert not over, "gradient rel-L2 error above the family cap: " + "; ".join(
+            f"{n}: hip {h:.2e} (cap {grad_caps[_family(n)]:.1e}) ref32 {r:.2e}" for _, h, r, g, n in over[:10])
+        worst_gross = max(report, key=lambda r: r[3] / grad_caps[_family(r[4])])
+        assert worst_gross[3] <= 10 * grad_caps[_family(worst_gross[4])], \
+            f"gross gradient mismatch: {worst_gross[4]} max-abs {worst_gross[3]:.2e}"
+        for name in grads:
+            ref_name = name.replace("ground_decoder.decoder.bbox_embed.", "bbox_embed.")
+            assert ref_name in rgrads, f"unexpected gradient for {name}"
+        return
     report.sort(reverse=True)
     summary = "; ".join(f"{n}: hip {h:.2e} ref32 {r:.2e} max {g:.2e}" for _, h, r, g, n in report[:10])
     assert not missing, f"parameters without a HIP gradient: {missing[:8]}"
@@ -235,7 +276,7 @@ def test_gpu_c1_forward_backward(golden_dir):
     g = np.load(os.path.join(golden_dir, "C1.npz"))
     keep, losses, grads = hip
     for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights"):
-        close(keep[k], torch.from_numpy(g[f"out/{k}"]), OUT_TOL, "golden " + k)
+        close(keep[k], torch.from_numpy(g[f"out/{k}"]), OUT_TOL, "golden " + k, absolute=True)
     assert keep["post_sted"] == g["post/sted"].tolist()
     close(keep["post_boxes"], torch.from_numpy(g["post/boxes"]), OUT_TOL, "golden post boxes")
     for k, v in zip(g["loss/keys"], g["loss/values"]):
@@ -253,13 +294,16 @@ def test_gpu_c1_split_bf16_modes(mma):
     T, res, L = synth.CONFIGS["C1"]
     g64 = _run_oracle(T, res, L, dtype=torch.float64)[4]
     _compare(_run_hip(dev, T, res, L, mma=mma), _run_oracle(T, res, L), g64=g64,
-             grad_slack=20.0 if mma == "bf16x3" else 1.0)
+             grad_caps=GRAD_CAPS_16BIT if mma == "bf16x3" else None)
 
 
 def test_emu_tiny_clip_bf16x3():
     dev = use_emu()
     g64 = _run_oracle(2, 64, 3, dtype=torch.float64)[4]
-    _compare(_run_hip(dev, 2, 64, 3, mma="bf16x3"), _run_oracle(2, 64, 3), g64=g64, grad_slack=20.0)
+    # T=2 frames of 64x64 (2x2 feature map): a tensor's gradient is a sum over a handful of tokens, so ONE flipped
+    # ReLU kink moves it by ~1e-2 — the tiny clip checks wiring, the calibrated caps apply at C1 / C3 on the GPU
+    _compare(_run_hip(dev, 2, 64, 3, mma="bf16x3"), _run_oracle(2, 64, 3), g64=g64,
+             grad_caps={k: min(8 * v, 5e-2) for k, v in GRAD_CAPS_16BIT.items()})
 
 
 @pytest.mark.gpu
@@ -287,6 +331,28 @@ def test_gpu_c3_full_size_forward():
     dev = use_hip()
     T, res, L = synth.CONFIGS["C3"]
     _compare(_run_hip(dev, T, res, L, with_backward=False, mma="bf16x3"), _run_oracle(T, res, L, with_backward=False),
+             with_backward=False)
+
+
+@pytest.mark.gpu
+def test_gpu_c3_full_size_forward_backward():
+    """The number bench.py sells is fwd + loss + BACKWARD at C3 in the 16-bit-operand arithmetic: check exactly that,
+    at full size, against the CPU oracle — outputs within an absolute 1e-3, span bit-exact, 30 loss terms, and every
+    gradient tensor within its family cap of the fp64 oracle run (the yardstick; ~100 s + ~150 s of host time)."""
+    dev = use_hip()
+    T, res, L = synth.CONFIGS["C3"]
+    hip = _run_hip(dev, T, res, L, mma=BENCH_MMA)
+    g64 = _run_oracle(T, res, L, dtype=torch.float64)[4]
+    _compare(hip, _run_oracle(T, res, L), g64=g64, grad_caps=GRAD_CAPS_16BIT)
+
+
+@pytest.mark.gpu
+def test_gpu_c5_full_size_forward():
+    """BASELINE configs[4] at FULL size: T=128, 448x448, 40 text tokens (S = 237 tokens per frame, 8 key tiles),
+    forward + PostProcess in the bench arithmetic against the CPU oracle."""
+    dev = use_hip()
+    T, res, L = synth.CONFIGS["C5"]
+    _compare(_run_hip(dev, T, res, L, with_backward=False, mma=BENCH_MMA), _run_oracle(T, res, L, with_backward=False),
              with_backward=False)
 
 

@@ -333,6 +333,41 @@ def _dropout_elementwise(dev, n, with_res):
     assert torch.equal(y3.cpu(), x * m3)
 
 
+@both
+def _dropout_stream_drop_in_mode(dev, big):
+    """in drop-in mode nothing calls dropout_begin_step / manual_seed.  The stream must (a) open a new
+    counter range by itself at the top of every train-mode forward, so the per-step range is never exhausted, and
+    (b) seed every DP rank differently by default."""
+    import os
+    S = ops._DropoutStream
+    ops.manual_seed(3)
+    x = rnd(64, seed=1).to(dev)
+    ops._dropout_stream.offset = S.STEP_SPAN - 64          # the host offset after ~190 C3 steps without a reset
+    base0 = int(ops._dropout_stream.base(dev).item())
+    ops.dropout_auto_begin_step(dev)                        # what Backbone.features_nhwc calls in train mode
+    assert ops.dropout_stream_state()[1] == 0
+    assert int(ops._dropout_stream.base(dev).item()) == base0 + S.STEP_SPAN
+    ops.dropout_auto_begin_step(dev)                        # nothing drawn since: not doubled
+    assert int(ops._dropout_stream.base(dev).item()) == base0 + S.STEP_SPAN
+    y = ops.dropout(x, 0.5)
+    assert ops.dropout_stream_state()[1] == 64 and torch.isfinite(y).all()
+    # default seeds: a function of torch.initial_seed() and the rank
+    seeds = []
+    old = os.environ.get("RANK")
+    try:
+        for r in ("0", "1"):
+            os.environ["RANK"] = r
+            ops._dropout_stream.seed = None
+            seeds.append(ops.dropout_stream_state()[0])
+    finally:
+        if old is None:
+            os.environ.pop("RANK", None)
+        else:
+            os.environ["RANK"] = old
+        ops.manual_seed(0)
+    assert seeds[0] != seeds[1]
+
+
 def _mha_dropout_case(dev, B, S, H, need_w, pdrop=0.25):
     D = H * 32
     SP = ((S + 31) // 32) * 32

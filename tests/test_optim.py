@@ -22,6 +22,9 @@ class _Toy(nn.Module):
         self.ground_decoder = nn.Module()
         self.ground_decoder.temp_decoder = nn.Linear(16, 3)
         self.rest = nn.Parameter(torch.randn(2, 65536 + 5))        # chunk boundary + tail
+        # a 3x3 conv weight in channels_last memory (physically OHWI), the layout of every backbone conv weight
+        # AND of its gradient (stcat_amd/backbone.py) — ADVICE r01: the standalone clip scrambled these
+        self.vis_encoder_conv = nn.Parameter(torch.randn(64, 64, 3, 3).contiguous(memory_format=torch.channels_last))
         self.frozen = nn.Parameter(torch.randn(9), requires_grad=False)
         self.unused = nn.Parameter(torch.randn(4))                  # never gets a gradient
 
@@ -48,7 +51,8 @@ def _reference_run(cfg, steps, decay):
     ema = copy.deepcopy(model)
     named = dict(model.named_parameters())
     groups = [{"params": [named["rest"], named["unused"]]},
-              {"params": [named["vis_encoder.weight"], named["vis_encoder.bias"]], "lr": cfg.SOLVER.VIS_BACKBONE_LR},
+              {"params": [named["vis_encoder.weight"], named["vis_encoder.bias"], named["vis_encoder_conv"]],
+               "lr": cfg.SOLVER.VIS_BACKBONE_LR},
               {"params": [named["text_encoder.weight"], named["text_encoder.bias"]], "lr": cfg.SOLVER.TEXT_LR},
               {"params": [named["ground_decoder.temp_decoder.weight"], named["ground_decoder.temp_decoder.bias"]],
                "lr": cfg.SOLVER.TEMP_LR}]
@@ -78,12 +82,13 @@ def _fused_tail(dev, big):
     model = _Toy().to(dev)
     ema = copy.deepcopy(model)
     opt = optim.make_optimizer(cfg, model)
-    assert [len(g["params"]) for g in opt.param_groups] == [2, 2, 2, 2]
+    assert [len(g["params"]) for g in opt.param_groups] == [2, 3, 2, 2]
     named = dict(model.named_parameters())
     for s in range(steps):
         opt.zero_grad()
         for n, g in _fake_grads(model, s).items():
-            named[n].grad = g.to(dev)
+            # gradients arrive in the parameter's own memory layout (channels_last for conv weights)
+            named[n].grad = torch.empty_like(named[n]).copy_(g.to(dev))
         sq = opt.step(max_grad_norm=cfg.SOLVER.MAX_GRAD_NORM, model_ema=ema, ema_decay=decay, model=model)
         assert abs(sq.sqrt().item() - ref_norms[s]) <= 1e-5 * ref_norms[s]
         optim.adjust_learning_rate(cfg, opt, s, 1000)
@@ -92,11 +97,25 @@ def _fused_tail(dev, big):
     for (n, p), (_, r) in zip(ema.named_parameters(), ref_ema.named_parameters()):
         close(p, r, 2e-6, "ema " + n)
     assert torch.equal(model.frozen.cpu(), ref_model.frozen) and torch.equal(model.unused.cpu(), ref_model.unused)
-    # checkpoint round trip of the moments
+    # checkpoint round trip of the moments, in torch.optim.AdamW's own layout (utils/checkpoint.py saves
+    # optimizer.state_dict()): ours loads into torch's optimizer and torch's loads into ours
     sd = opt.state_dict()
     opt2 = optim.make_optimizer(cfg, model)
     opt2.load_state_dict(sd)
     assert opt2.step_count == steps and len(opt2.state) == len(opt.state)
+    cpu_model = _Toy()
+    topt = torch.optim.AdamW([{"params": g["params"]} for g in optim.make_optimizer(cfg, cpu_model).param_groups],
+                             lr=cfg.SOLVER.BASE_LR)
+    topt.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                          "param_groups": sd["param_groups"]})
+    tsd = topt.state_dict()
+    assert all(int(v["step"]) == steps for v in tsd["state"].values())
+    opt3 = optim.make_optimizer(cfg, model)
+    opt3.load_state_dict(tsd)
+    assert opt3.step_count == steps
+    conv = dict(model.named_parameters())["vis_encoder_conv"]
+    close(opt3.state[conv]["exp_avg"], opt.state[conv]["exp_avg"], 1e-7, "reloaded channels_last moment")
+    assert opt3.state[conv]["exp_avg"].stride() == conv.stride()
 
 
 @both
@@ -110,7 +129,8 @@ def _standalone_clip_and_ema(dev, big):
     model = model.to(dev)
     for (n, p), (_, r) in zip(model.named_parameters(), ref.named_parameters()):
         if r.grad is not None:
-            p.grad = r.grad.clone().to(dev)
+            p.grad = torch.empty_like(p).copy_(r.grad.to(dev))     # parameter's layout (channels_last conv grads)
+            assert p.grad.stride() == p.stride()
     n_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
     n_hip = optim.clip_grad_norm_(model.parameters(), 0.1)
     assert abs(n_hip.item() - n_ref.item()) <= 1e-5 * n_ref.item()
