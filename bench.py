@@ -55,6 +55,11 @@ def _flops(name, a):
         n, H, W, Cin, Cout, KH, KW, stride, pad = a[3:12]
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin
+    if name in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad", "stcat_pl_conv_wgrad"):
+        o = {"stcat_pl_conv_fwd": 11, "stcat_pl_conv_dgrad": 14, "stcat_pl_conv_wgrad": 5}[name]
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[o:o + 9]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        return 2.0 * n * OH * OW * Cout * KH * KW * Cin
     if name == "stcat_stem_fwd":
         n, H, W = a[5:8]
         return 2.0 * n * (H // 2) * (W // 2) * 64 * 147
@@ -171,7 +176,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
-    ap.add_argument("--mma", default="bf16x3", choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--mma", default="bf16x3p", choices=["f32", "bf16x3", "bf16x6", "bf16x3p"],
                     help="arithmetic of the conv/Linear GEMM family (fp32 tensors in HBM in every mode); bf16x3 is the "
                          "split-product parity mode of SURVEY.md §7 hard part 3 (meets the 1e-3 / bit-exact-span bars)")
     ap.add_argument("--eval-mode", action="store_true",
@@ -312,7 +317,12 @@ def main():
         # dominant KERNEL: in the split-bf16 modes the conv forward and the conv data gradient (pre-transposed
         # weights) are the same device kernel, igemm_bs_fwd_kernel<128,128,NS> — price them together
         fam = dict(agg)
-        if args.mma != "f32" and "stcat_conv_fwd" in agg and "stcat_conv_dgrad" in agg:
+        if args.mma == "bf16x3p" and "stcat_pl_conv_fwd" in agg and "stcat_pl_conv_dgrad" in agg:
+            a, b = agg["stcat_pl_conv_fwd"], agg["stcat_pl_conv_dgrad"]
+            fam = {k: v for k, v in agg.items() if k not in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad")}
+            fam["igemm_pl_fwd_kernel (stcat_pl_conv_fwd + stcat_pl_conv_dgrad)"] = {
+                "launches": a["launches"] + b["launches"], "ms": a["ms"] + b["ms"], "flop": a["flop"] + b["flop"]}
+        elif args.mma != "f32" and "stcat_conv_fwd" in agg and "stcat_conv_dgrad" in agg:
             a, b = agg["stcat_conv_fwd"], agg["stcat_conv_dgrad"]
             fam = {k: v for k, v in agg.items() if k not in ("stcat_conv_fwd", "stcat_conv_dgrad")}
             fam["igemm_bs_fwd_kernel (stcat_conv_fwd + stcat_conv_dgrad)"] = {
@@ -321,7 +331,7 @@ def main():
         d = fam[dom]
         ach = d["flop"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
         # roofline in ISSUED matrix flops: algorithmic flops x (1 | 3 | 6) against the pipe that executes them
-        mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6}[args.mma]
+        mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6, "bf16x3p": 3}[args.mma]
         peak = PEAK_TFLOPS_F32_MFMA if args.mma == "f32" else PEAK_TFLOPS_BF16_MFMA
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach * mult, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach * mult / peak, 4), "traffic": None,
@@ -392,7 +402,9 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
-                      "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate"}[args.mma], "data": "synthetic",
+                      "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate",
+                      "bf16x3p": "bf16x3 split products, f32 accumulate; backbone tensors stored as bf16 hi+lo planes "
+                                 "(16 significand bits), everything else f32"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",

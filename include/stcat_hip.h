@@ -31,6 +31,8 @@ const char* stcat_last_error(void);
  *   3 = split-bf16 x6: three bf16 pieces, six cross terms (fp32-class products) */
 int stcat_set_mma_mode(int mode);
 int stcat_get_mma_mode(void);
+/*   4 = split-bf16 x3 with the backbone's activations, gradients and weights PRE-SPLIT into bf16 planes in HBM (the
+ *       stcat_pl_* entry points below); every other GEMM of the path runs as mode 2 */
 /* tuning/test hook: force the implicit-GEMM block tile (128x128, 128x64, 64x64; 0,0 = heuristic) */
 int stcat_debug_force_tile(int bm, int bn);
 /* stream-K scheduling of the split-bf16 forward GEMM (opt-in experiment): 1 whenever legal,
@@ -76,6 +78,48 @@ int stcat_conv_wgrad(const float* g, const float* x, float* dw, int n, int H, in
 /* backward of y = relu?(scale*z + bias (+res)): dz = dy*[y>0]; G = dz*scale[c] (may be NULL); dres = dz (may be NULL) */
 int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G, float* dres, long n, int C,
                   int relu, void* stream);
+
+/* ---- plane-format backbone (stcat_set_mma_mode(4)) -------------------------------------------------
+ * Same call sites as the stcat_conv_* family above (torchvision resnet101 inside
+ * models/vision_model/backbone.py:115-119, FrozenBatchNorm2d :56-66, autograd of conv2d), but every tensor is a
+ * PAIR of bf16 planes (h, l) with x = h + l, h = bf16(x), l = bf16(x - h): NHWC [n,H,W,C] per plane, weights OHWI per
+ * plane.  The split is done once by the producing kernel's epilogue, so the GEMM main loop moves operands
+ * HBM -> LDS by LDS-DMA and issues nothing but fragment reads and MFMAs (stcat_amd/csrc/igemm_pl.h).
+ * Products are hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (= mode 2 arithmetic). */
+/* y = relu?(scale*conv(x,w) + bias + res): planes in, planes (yh, yl) and/or fp32 (yf) out; res planes optional */
+int stcat_pl_conv_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* scale,
+                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf, int n, int H,
+                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream);
+/* dx = conv_transpose(g, w) (+ add), then the fused ReLU + FrozenBN backward of the layer below (y planes,
+ * mask_scale) and the optional second output dx2 = dx * dx2_scale — semantics of stcat_conv_dgrad.  th / tl are the
+ * TRANSPOSED weight planes [taps][Cin][Cout] written by stcat_weight_planes_multi. */
+int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const void* tl, const void* addh,
+                        const void* addl, const void* yh, const void* yl, const float* mask_scale, void* dxh, void* dxl,
+                        void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int stride, int pad, void* stream);
+/* dw (fp32 OHWI, caller-zeroed) += sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0 */
+int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, int n, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* resnet maxpool 3x3/2 pad 1: fp32 NHWC in (stem output) -> planes out */
+int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int W, int C, void* stream);
+/* fp32 <-> planes; n % 8 == 0 */
+int stcat_pl_split(const float* x, void* h, void* l, long n, void* stream);
+int stcat_pl_join(const void* h, const void* l, float* out, long n, void* stream);
+/* stcat_act_bwd with plane outputs: dz = dy * [y > 0] (dy, y fp32; relu = 0: no mask) -> (rh, rl) if given;
+ * g = dz * scale[c] -> (gh, gl) if given */
+int stcat_pl_act_bwd(const float* dy, const float* y, const float* scale, void* gh, void* gl, void* rh, void* rl, long n,
+                     int C, int relu, void* stream);
+/* g = x * scale[c] on planes (upstream gradient of a downsample conv: dz * FrozenBN scale) */
+int stcat_pl_scale(const void* xh, const void* xl, const float* scale, void* gh, void* gl, long n, int C, void* stream);
+/* weight planes for many conv weights in ONE launch: DEVICE table of entries
+ *   { const float* w; bf16* wh, *wl, *th, *tl; int Cout, taps, Cin; int blk0, nbx, nby; int pad; }
+ * (stcat_weight_planes_entry_bytes() == 72): w fp32 OHWI -> (wh, wl) OHWI planes and, when th != NULL, the transposed
+ * planes (th, tl) [taps][Cin][Cout]; entry e owns grid blocks [blk0, blk0 + nbx*nby*taps), nbx = ceil(Cin/32),
+ * nby = ceil(Cout/32), blk0 ascending */
+int stcat_weight_planes_entry_bytes(void);
+int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream);
+/* tuning/test hook: force the plane-GEMM tile (0: 256x256, 1: 256x128, 2: 128x256, 3: 128x128, 4: 256x64; -1 = heuristic) */
+int stcat_debug_force_pl_tile(int index);
 
 /* ---- position embeddings ------------------------------------------------------------------------ */
 /* PositionEmbeddingSine(128, normalize=True) (vision_model/position_encoding.py:70-94):

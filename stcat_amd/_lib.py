@@ -53,6 +53,17 @@ SIGNATURES: Dict[str, str] = {
     "stcat_ema_update": "pppiifs",
     "stcat_optim_table_entry_bytes": "",
     "stcat_temporal_map_argmax": "pppiis",
+    "stcat_pl_conv_fwd": "ppppppppppp" + "iiiiiiiiii" + "s",
+    "stcat_pl_conv_dgrad": "pppppppppppppp" + "iiiiiiiii" + "s",
+    "stcat_pl_conv_wgrad": "ppppp" + "iiiiiiiii" + "s",
+    "stcat_pl_maxpool3x3s2": "pppiiiis",
+    "stcat_pl_split": "pppls",
+    "stcat_pl_join": "pppls",
+    "stcat_pl_act_bwd": "ppppppp" + "lii" + "s",
+    "stcat_pl_scale": "ppppplis",
+    "stcat_weight_planes_entry_bytes": "",
+    "stcat_weight_planes_multi": "piis",
+    "stcat_debug_force_pl_tile": "i",
     "stcat_debug_force_tile": "ii",
     "stcat_debug_streamk": "i",
     "stcat_set_mma_mode": "i",
@@ -104,12 +115,14 @@ def backend() -> str:
     return _backend
 
 
-MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
+MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "bf16x3p": 4}
 
 
 def set_mma_mode(mode: str) -> None:
     """Arithmetic of the conv / Linear GEMM family: 'f32' (exact fp32 MFMA), 'bf16x3' or 'bf16x6'
-    (fp32 operands split into bf16 pieces on the bf16 matrix pipe, fp32 accumulate)."""
+    (fp32 operands split into bf16 pieces on the bf16 matrix pipe, fp32 accumulate), or 'bf16x3p': the bf16x3
+    arithmetic with the backbone's activations / gradients / weights kept PRE-SPLIT as bf16 hi/lo planes in HBM
+    (csrc/igemm_pl.h: LDS-DMA staged 256-wide tiles); all other GEMMs run as 'bf16x3'."""
     call("stcat_set_mma_mode", MMA_MODES[mode])
 
 

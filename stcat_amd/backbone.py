@@ -73,6 +73,7 @@ class ResNet101Body(nn.Module):
     def __init__(self):
         super().__init__()
         self._wt_cache = ops.WeightTransposer()  # transposed conv weights for the data-gradient GEMMs (backward)
+        self._wpl_cache = ops.WeightPlanes()     # bf16 hi/lo planes of every conv weight (mma mode "bf16x3p")
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(64)
         inplanes = 64
@@ -174,6 +175,88 @@ class _BackboneFn(Function):
         return (None, None, *out)
 
 
+class _BackboneFnPl(Function):
+    """The same network in mma mode "bf16x3p": every activation / gradient / weight between the max-pool and the layer4
+    output is a pair of bf16 planes (ops.Planes) written by the producing kernel's epilogue and consumed by the
+    LDS-DMA staged plane GEMMs (csrc/igemm_pl.h).  The layer4 output leaves as fp32 (consumer: input_proj)."""
+
+    @staticmethod
+    def forward(ctx, frames, body: ResNet101Body, *weights):
+        need_bwd = any(w.requires_grad for w in weights)
+        s, b = body.bn1.folded()
+        x = ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+        x = ops.pl_maxpool_raw(x)
+        blocks = list(body.blocks())
+        ws = []
+        for _, blk in blocks:
+            ws += [_ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)]
+            if blk.downsample is not None:
+                ws.append(_ohwi(blk.downsample[0].weight))
+        wp, wt = body._wpl_cache.refresh(ws, transposed=need_bwd)
+        tape = []
+        yf = None
+        for bi, (li, blk) in enumerate(blocks):
+            last = bi == len(blocks) - 1
+            w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
+            s1, b1 = blk.bn1.folded()
+            s2, b2 = blk.bn2.folded()
+            s3, b3 = blk.bn3.folded()
+            o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True)
+            o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True)
+            wd = sd = None
+            if blk.downsample is not None:
+                wd = _ohwi(blk.downsample[0].weight)
+                sd, bd = blk.downsample[1].folded()
+                idt, _ = ops.pl_conv_fwd_raw(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
+            else:
+                idt = x
+            y, yf = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last)
+            if need_bwd and blk.conv1.weight.requires_grad:
+                tape.append((blk, x, o1, o2, yf if last else y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
+            x = y
+        ctx.tape = tape
+        ctx.wt = wt
+        ctx.body = body
+        return yf
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = {}
+        tape, wt = ctx.tape, ctx.wt
+        _wt = lambda w: wt[w.data_ptr()]  # noqa: E731
+        blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
+        # top of the stack (y is the fp32 layer4 output): dz = dy * [y > 0], g3 = dz * scale3 — both as planes
+        g3, dz = ops.pl_act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
+        for idx in range(len(tape) - 1, -1, -1):
+            blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd) = tape[idx]
+            need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
+            grads[id(blk.conv3.weight)] = ops.pl_conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
+            g2 = ops.pl_conv_dgrad_raw(g3, _wt(w3), o2.shape, 1, 1, 0, mask_y=o2, mask_scale=s2)
+            grads[id(blk.conv2.weight)] = ops.pl_conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
+            g1 = ops.pl_conv_dgrad_raw(g2, _wt(w2), o1.shape, 3, blk.stride, 1, mask_y=o1, mask_scale=s1)
+            grads[id(blk.conv1.weight)] = ops.pl_conv_wgrad_raw(g1, x, w1.shape, 1, 0)
+            gd = None
+            if wd is not None:
+                gd = ops.pl_scale_raw(dz, sd)  # dz * scale_downsample
+                grads[id(blk.downsample[0].weight)] = ops.pl_conv_wgrad_raw(gd, x, wd.shape, blk.stride, 0)
+            if not need_dx:
+                break
+            s3_below = tape[idx - 1][6][2]
+            if wd is not None:
+                part = ops.pl_conv_dgrad_raw(gd, _wt(wd), x.shape, 1, blk.stride, 0)
+                dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=part, out=part, mask_y=x,
+                                               scale2=s3_below)
+            else:
+                dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=dz, mask_y=x, scale2=s3_below)
+        out = []
+        for w in ctx.body.parameters():
+            g = grads.get(id(w))
+            out.append(g.permute(0, 3, 1, 2) if g is not None else None)
+        ctx.tape = None
+        ctx.wt = None
+        return (None, None, *out)
+
+
 class Backbone(nn.Module):
     """BackboneBase + Backbone (backbone.py:69-121): ``body`` holds the ResNet, layer2-4 are trainable."""
 
@@ -195,6 +278,8 @@ class Backbone(nn.Module):
             # no other place to do it — the reference's train loop is unmodified)
             ops.dropout_auto_begin_step(frames.device)
         weights = [p for p in self.body.parameters()]
+        if ops.L.get_mma_mode() == "bf16x3p":
+            return _BackboneFnPl.apply(frames, self.body, *weights)
         return _BackboneFn.apply(frames, self.body, *weights)
 
     def forward(self, tensor_list: NestedTensor):

@@ -1,0 +1,605 @@
+// Plane-format split-bf16 implicit GEMM for the ResNet-101 conv stack (torchvision resnet101 call site
+// models/vision_model/backbone.py:115-119, FrozenBN :56-66) — round-2 rebuild of the dominant kernel.
+//
+// Arithmetic is the bf16x3 contraction of igemm_bs.h (x = hi + lo in bf16; hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate), but the operands ARRIVE split: every activation / gradient / weight
+// of the backbone lives in HBM as two bf16 planes (hi = bf16(x), lo = bf16(x - hi); 4 bytes per element like fp32),
+// written that way by the producing epilogue.  What that buys in the K loop (measured, tools/proto/gemm_pl_probe.hip,
+// profiles/r02_gemm_pl_probe.log):
+//   * operands go HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane): no staging VGPRs, no fp32->bf16 split
+//     VALU, no ds_write pass; padding / stride-lattice / tail rows are the descriptor's out-of-range zero fill;
+//   * 256-wide tiles, 8 waves, ONE workgroup per CU: per K-step of 32 a wave issues 48 MFMAs against 24 ds_read_b128
+//     and 8 DMA instructions (the 128x128 4-wave kernel: 24 MFMAs against 16 reads + 16 loads + ~100 split VALU);
+//   * fragments are double-buffered across k-steps AND K-tiles (the reads of step s+1 are issued among the MFMAs of
+//     step s), one barrier per K-tile, the DMA of tile t+2 is issued among the MFMAs that follow the barrier of
+//     tile t+1 and is waited for one whole tile later (two tiles in flight: two 64 KB stages);
+//   * LDS rows are 64 B (32 bf16) with the 16-byte chunk index XOR-ed by (row >> 2) & 3 — applied to the per-lane
+//     SOURCE address of the DMA (its destination is lane-linear) and to the fragment read: conflict-free for the
+//     16-lane groups of ds_read_b128.
+// Plain-GEMM form of this loop at 8192 x 8192 x 2304: 433-440 TF algorithmic = 1.3 PF issued (52 % of the dense
+// bf16 peak; the MFMA-only ceiling of the same wave tile on random data is 588 TF) against 320-330 TF for igemm_bs.h.
+//
+// Epilogue: accumulators -> wave-private LDS block -> whole 16-byte row segments per lane: FrozenBN scale/bias,
+// residual (planes), ReLU, fused ReLU+BN backward mask of the layer below (dgrad), second scaled output, then the
+// hi/lo split and 16-byte plane stores (and/or an fp32 store for the consumer outside the backbone).
+//
+// The weight gradient (igemm_pl_wgrad_kernel) contracts over pixels: both operands are k-major in HBM.  They are
+// staged as they lie ([32 pixels][BM or BN channels]) and transposed on the way to the MFMA by ds_read_b64_tr_b16.
+#pragma once
+#include "igemm.h"
+
+struct PlParams {
+  const __bf16* Ah; const __bf16* Al;   // gathered operand planes: NHWC pixels, pixel stride g.ld elements
+  const __bf16* Bh; const __bf16* Bl;   // weight planes: row = output column n (stride ldb elements); K-tile (tap, c0) at
+                                        // element offset tap * b_tap_stride + c0 inside a row
+  __bf16* Ch; __bf16* Cl;               // output planes [M][ldc] (both or neither)
+  float* Cf;                            // fp32 output [M][ldc] or null
+  const float* scale; const float* bias;
+  const __bf16* Rh; const __bf16* Rl;   // residual planes [M][ldr] or null
+  const __bf16* Yh; const __bf16* Yl;   // dgrad: planes of y [M][ldc] (output of the layer below): result zeroed where y <= 0 ...
+  const float* mscale;                  // ... and multiplied by that layer's FrozenBN scale (or null)
+  __bf16* C2h; __bf16* C2l; const float* c2scale;  // optional second output C * c2scale[n]
+  int M, N, K, ldb, ldc, ldr, relu;
+  unsigned a_bytes, b_bytes;            // extent of ONE plane of A / B (bytes)
+  unsigned b_tap_stride;                // elements
+  int k_chunk;                          // wgrad: pixels of the reduction per grid.z slice (multiple of 32)
+  float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
+  IgemmGeom g;
+};
+
+static __device__ __forceinline__ void stcat_split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hh = (__bf16)v[e];
+    h[e] = hh;
+    l[e] = (__bf16)(v[e] - (float)hh);
+  }
+}
+static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf16* lp, float (&v)[8]) {
+  const bf16x8 h = *reinterpret_cast<const bf16x8*>(hp), l = *reinterpret_cast<const bf16x8*>(lp);
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) v[e] = (float)h[e] + (float)l[e];
+}
+
+#define STCAT_PL_ACC_INIT                                     \
+  f32x16 acc[TM][TN];                                         \
+  STCAT_UNROLL                                                \
+  for (int i = 0; i < TM; ++i) {                              \
+    STCAT_UNROLL                                              \
+    for (int j = 0; j < TN; ++j) {                            \
+      STCAT_UNROLL                                            \
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;        \
+    }                                                         \
+  }
+
+// 3 MFMA groups of one k-step (16 reduction terms); split terms outermost so consecutive MFMAs hit different accumulators
+#define STCAT_PL_MMA(F)                                                                                 \
+  STCAT_UNROLL                                                                                          \
+  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+    STCAT_UNROLL                                                                                        \
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.al[tm], F.bh[tn], acc[tm][tn]); \
+  }                                                                                                     \
+  STCAT_UNROLL                                                                                          \
+  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+    STCAT_UNROLL                                                                                        \
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.ah[tm], F.bl[tn], acc[tm][tn]); \
+  }                                                                                                     \
+  STCAT_UNROLL                                                                                          \
+  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+    STCAT_UNROLL                                                                                        \
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.ah[tm], F.bh[tn], acc[tm][tn]); \
+  }
+
+// interleave request for the block [DMA | fragment reads | MFMAs] that follows: NV DMA instructions and ND fragment
+// reads spread over NM MFMAs.  Measured (probe V8/V9): with the 8 DMA instructions clustered behind the barrier both
+// waves of a SIMD sit in address/M0 set-up while the matrix pipe idles (-12 %).
+#define STCAT_PL_INTERLEAVE(NM, ND, NV)                                                                 \
+  STCAT_UNROLL                                                                                          \
+  for (int i_ = 0; i_ < (NV); ++i_) { STCAT_SCHED_GROUP(0x008, 1); STCAT_SCHED_GROUP(0x020, 1); }       \
+  STCAT_UNROLL                                                                                          \
+  for (int i_ = 0; i_ < (ND); ++i_) {                                                                   \
+    STCAT_SCHED_GROUP(0x008, ((NM) - (NV)) / (ND) > 0 ? ((NM) - (NV)) / (ND) : 1);                      \
+    STCAT_SCHED_GROUP(0x100, 1);                                                                        \
+  }
+
+// ---------------------------------------------------------------------------------------------------
+// forward / data gradient:  C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (tap, c), c fastest
+// 8 waves as WM x WN, wave tile (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32 x 32.
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;            // bytes: rows x 64 B
+  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;               // Ah, Al, Bh, Bl
+  constexpr int QA = BM / 16, QB = BN / 16;                      // 1-KiB DMA pieces (16 rows) per plane
+  constexpr int RQA = (QA + 7) / 8, RQB = (QB + 7) / 8;          // pieces per wave
+  constexpr int LDE = TN * 32 + 4;                               // epilogue block: 32 rows x (TN*32) fp32, padded
+  constexpr int EPI_WAVE = 32 * LDE * 4;
+  static_assert(8 * EPI_WAVE <= 2 * STAGE, "epilogue blocks fit the operand stages");
+  STCAT_DYN_SHARED(char, smem);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int wq = STCAT_READFIRSTLANE(wave);
+  const int wm = wave / WN, wn = wave % WN;
+  const int num_n = p.N / BN;
+  const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;
+  const IgemmGeom g = p.g;
+  const int nk = p.K / BK;
+
+  // ---- DMA bookkeeping: piece q = wave + 8 i covers rows 16 q .. 16 q + 15 of a plane; lane -> row 16 q + (lane >> 2),
+  // LDS chunk (lane & 3) which holds SOURCE chunk (lane & 3) ^ ((row >> 2) & 3)
+  int a_nb[RQA], a_bh[RQA], a_bw[RQA];
+  unsigned a_c16[RQA], b_voff[RQB];
+  STCAT_UNROLL
+  for (int i = 0; i < RQA; ++i) {
+    const int q = wave + 8 * i, r = q * 16 + (lane >> 2), m = m0 + r;
+    a_c16[i] = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16);
+    a_nb[i] = -1; a_bh[i] = 0; a_bw[i] = 0;
+    if (q < QA && m < p.M) {
+      const int nb = stcat_fastdiv(m, g.mg_ohw, g.sh_ohw), rem = m - nb * g.OH * g.OW;
+      const int oh = stcat_fastdiv(rem, g.mg_ow, g.sh_ow), ow = rem - oh * g.OW;
+      a_nb[i] = nb; a_bh[i] = oh * g.mul + g.off; a_bw[i] = ow * g.mul + g.off;
+    }
+  }
+  STCAT_UNROLL
+  for (int i = 0; i < RQB; ++i) {
+    const int q = wave + 8 * i, r = q * 16 + (lane >> 2);
+    b_voff[i] = q < QB ? (unsigned)(((n0 + r) * p.ldb) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16) : STCAT_BUF_OOB;
+  }
+  // load cursor: K-tile kl = (tap (kh, kw), channel offset c0); advances one tile per stage_load.  Tiles past the end
+  // go through zero-length descriptors (zero fill into a stage nobody reads): the loop body stays branch-free, which
+  // keeps the compiler's wait counts exact.
+  int kl = 0, l_c0 = 0, l_kh = 0, l_kw = 0, l_tap = 0;
+  const int dmask = g.div - 1, dshift = g.div > 1 ? 31 - __builtin_clz(g.div) : 0;  // div is 1 or a power of two
+#define STCAT_PL_STAGE_LOAD(ST)                                                                         \
+  {                                                                                                     \
+    const bool live_ = kl < nk;                                                                         \
+    const stcat_buf_t dAh_ = stcat_make_buf(p.Ah, live_ ? p.a_bytes : 0u), dAl_ = stcat_make_buf(p.Al, live_ ? p.a_bytes : 0u); \
+    const stcat_buf_t dBh_ = stcat_make_buf(p.Bh, live_ ? p.b_bytes : 0u), dBl_ = stcat_make_buf(p.Bl, live_ ? p.b_bytes : 0u); \
+    const unsigned soA_ = (unsigned)l_c0 * 2u, soB_ = ((unsigned)l_tap * p.b_tap_stride + (unsigned)l_c0) * 2u; \
+    char* base_ = smem + (ST) * STAGE + wq * 1024;                                                      \
+    STCAT_UNROLL                                                                                        \
+    for (int i = 0; i < RQA; ++i) {                                                                     \
+      int h_ = a_bh[i] + l_kh * g.sgn, w_ = a_bw[i] + l_kw * g.sgn;                                     \
+      bool ok_ = (a_nb[i] >= 0) & (((h_ | w_) & dmask) == 0);                                           \
+      h_ >>= dshift; w_ >>= dshift;                                                                     \
+      ok_ = ok_ & ((unsigned)h_ < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);                      \
+      const unsigned vo_ = ok_ ? (unsigned)(((a_nb[i] * g.H + h_) * g.W + w_) * g.ld) * 2u + a_c16[i] : STCAT_BUF_OOB; \
+      if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
+        stcat_glds16(dAh_, base_ + i * 8192, vo_, soA_);                                                \
+        stcat_glds16(dAl_, base_ + PLANE_A + i * 8192, vo_, soA_);                                      \
+      }                                                                                                 \
+    }                                                                                                   \
+    STCAT_UNROLL                                                                                        \
+    for (int i = 0; i < RQB; ++i) {                                                                     \
+      if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
+        stcat_glds16(dBh_, base_ + 2 * PLANE_A + i * 8192, b_voff[i], soB_);                            \
+        stcat_glds16(dBl_, base_ + 2 * PLANE_A + PLANE_B + i * 8192, b_voff[i], soB_);                  \
+      }                                                                                                 \
+    }                                                                                                   \
+    ++kl; l_c0 += BK;                                                                                   \
+    if (l_c0 == g.C) { l_c0 = 0; ++l_tap; ++l_kw; if (l_kw == g.KW) { l_kw = 0; ++l_kh; } }             \
+  }
+
+  // ---- fragment addressing: lane -> row l31 of its tile, k-step ks -> chunk (2 ks + hi) ^ ((row >> 2) & 3)
+  unsigned fa_off[2], fb_off[2];
+  STCAT_UNROLL
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c = ks * 2 + hi, sw = (l31 >> 2) & 3;
+    fa_off[ks] = (unsigned)((wm * TM * 32 + l31) * 64 + ((c ^ sw) * 16));
+    fb_off[ks] = (unsigned)(2 * PLANE_A + (wn * TN * 32 + l31) * 64 + ((c ^ sw) * 16));
+  }
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+#define STCAT_PL_READ_FRAG(F, SB, KS)                                                                   \
+  STCAT_UNROLL                                                                                          \
+  for (int tn = 0; tn < TN; ++tn) {                                                                     \
+    F.bh[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + tn * 2048);                         \
+    F.bl[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + PLANE_B + tn * 2048);               \
+  }                                                                                                     \
+  STCAT_UNROLL                                                                                          \
+  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+    F.ah[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + tm * 2048);                         \
+    F.al[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + PLANE_A + tm * 2048);               \
+  }
+
+  STCAT_PL_ACC_INIT
+  constexpr int NMMA = 3 * TM * TN, NRD = 2 * (TM + TN);
+  constexpr int NDMA = 2 * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  Frag fa, fb;
+  STCAT_PL_STAGE_LOAD(0)
+  STCAT_PL_STAGE_LOAD(1)
+  STCAT_WAIT_VM0();      // tiles 0 and 1 landed (once per workgroup: a counted wait would differ per wave when a plane
+  STCAT_S_BARRIER();     // has fewer than 8 DMA pieces)
+  STCAT_SCHED_FENCE();
+  STCAT_PL_READ_FRAG(fa, smem, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * STAGE;
+    const char* sn = smem + ((kt + 1) & 1) * STAGE;
+    // P0: k-step 1 fragments are read among the MFMAs of k-step 0
+    STCAT_PL_READ_FRAG(fb, sb, 1)
+    STCAT_PL_INTERLEAVE(NMMA, NRD, 0)
+    STCAT_PL_MMA(fa)
+    STCAT_SCHED_FENCE();
+    // P1: own reads of this stage are back (the MFMAs below need fb anyway), tile kt+1 has landed, and after the
+    // barrier every wave is past its reads of this stage: its buffer takes tile kt+2
+    STCAT_WAIT_VM0_LGKM0();
+    STCAT_S_BARRIER();
+    STCAT_SCHED_FENCE();
+    STCAT_PL_STAGE_LOAD(kt & 1)
+    STCAT_PL_READ_FRAG(fa, sn, 0)
+    STCAT_PL_INTERLEAVE(NMMA, NRD, NDMA)
+    STCAT_PL_MMA(fb)
+    STCAT_SCHED_FENCE();
+  }
+#undef STCAT_PL_STAGE_LOAD
+#undef STCAT_PL_READ_FRAG
+  STCAT_WAIT_VM0_LGKM0();  // past-the-end DMA (zero fill) has landed too: the stages are reused below
+  STCAT_S_BARRIER();
+  STCAT_SCHED_FENCE();
+
+  // ---- epilogue: per wave, one 32-row block of its tile at a time through a private LDS block
+  float* ew = reinterpret_cast<float*>(smem + wave * EPI_WAVE);
+  constexpr int LPR = TN * 4;          // lanes per output row (8 columns each)
+  constexpr int RPP = 64 / LPR;        // rows per pass
+  const int erow = lane / LPR, ecol = (lane % LPR) * 8;
+  const int n = n0 + wn * TN * 32 + ecol;
+  float sc[8], bi[8], ms[8], s2[8];
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = p.scale ? p.scale[n + e] : 1.f;
+    bi[e] = p.bias ? p.bias[n + e] : 0.f;
+    ms[e] = p.mscale ? p.mscale[n + e] : 1.f;
+    s2[e] = p.c2scale ? p.c2scale[n + e] : 1.f;
+  }
+  STCAT_UNROLL
+  for (int tm = 0; tm < TM; ++tm) {
+    STCAT_UNROLL
+    for (int tn = 0; tn < TN; ++tn) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDE + tn * 32 + l31] = acc[tm][tn][r];
+    }
+    STCAT_WAVE_LDS_FENCE();
+    STCAT_UNROLL
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+      const int row = ps * RPP + erow;
+      const int m = m0 + wm * TM * 32 + tm * 32 + row;
+      const float4 v0 = stcat_ld4(&ew[row * LDE + ecol]), v1 = stcat_ld4(&ew[row * LDE + ecol + 4]);
+      float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (m < p.M) {
+        STCAT_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
+        if (p.Rh) {
+          float rr[8];
+          stcat_join8(p.Rh + (long)m * p.ldr + n, p.Rl + (long)m * p.ldr + n, rr);
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] += rr[e];
+        }
+        if (p.relu) {
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        if (p.Yh) {
+          float yy[8];
+          stcat_join8(p.Yh + (long)m * p.ldc + n, p.Yl + (long)m * p.ldc + n, yy);
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] = yy[e] > 0.f ? x[e] * ms[e] : 0.f;
+        }
+        if (p.Ch) {
+          bf16x8 h8, l8;
+          stcat_split8(x, h8, l8);
+          *reinterpret_cast<bf16x8*>(p.Ch + (long)m * p.ldc + n) = h8;
+          *reinterpret_cast<bf16x8*>(p.Cl + (long)m * p.ldc + n) = l8;
+        }
+        if (p.Cf) {
+          stcat_st4(p.Cf + (long)m * p.ldc + n, make_float4(x[0], x[1], x[2], x[3]));
+          stcat_st4(p.Cf + (long)m * p.ldc + n + 4, make_float4(x[4], x[5], x[6], x[7]));
+        }
+        if (p.C2h) {
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] *= s2[e];
+          bf16x8 h8, l8;
+          stcat_split8(x, h8, l8);
+          *reinterpret_cast<bf16x8*>(p.C2h + (long)m * p.ldc + n) = h8;
+          *reinterpret_cast<bf16x8*>(p.C2l + (long)m * p.ldc + n) = l8;
+        }
+      }
+    }
+    STCAT_WAVE_LDS_FENCE();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight gradient:  dW[co][(tap, ci)] += sum over pixels m of dY[m][co] * X[pix(m, tap)][ci]
+//   rows = co (BM), columns = (tap, ci) (BN, inside one tap: C % BN == 0), reduction = pixels, split over grid.z.
+// Both operands are k-major in HBM (a pixel is a row of channels): they are staged as [32 pixels][BM | BN channels]
+// images and the MFMA fragments (8 consecutive k per lane) come out of ds_read_b64_tr_b16.  A k-row is BM*2 (BN*2)
+// bytes; its 64-byte segments are XOR-ed with (k & 3) inside each 256-byte group, so the four k-rows that one
+// transposing read touches sit in four different bank quarters.
+// ---------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
+  static_assert(WM * WN == 8, "8 waves");
+  static_assert(BM % 128 == 0 && BN % 128 == 0, "a k-row is a whole number of 256-byte groups");
+  constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int ROWA = BM * 2, ROWB = BN * 2;                    // bytes per k-row
+  constexpr int PLANE_A = BK * ROWA, PLANE_B = BK * ROWB;
+  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  constexpr int QA = PLANE_A / 1024, QB = PLANE_B / 1024;        // 1-KiB DMA pieces per plane
+  constexpr int RQA = (QA + 7) / 8, RQB = (QB + 7) / 8;
+  constexpr int LA = ROWA / 16, LB = ROWB / 16;                  // lanes (16-byte chunks) per k-row
+  STCAT_DYN_SHARED(char, smem);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, hi = lane >> 5;
+  const int wq = STCAT_READFIRSTLANE(wave);
+  const int wm = wave / WN, wn = wave % WN;
+  const int num_n = p.N / BN;
+  const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;        // m0: first co, n0: first (tap, ci) column
+  const IgemmGeom g = p.g;
+  const int tap = n0 / g.C, ci0 = n0 - tap * g.C;
+  const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  const int red0 = blockIdx.z * p.k_chunk;
+  const int red1 = min(p.K, red0 + p.k_chunk);
+  const int nk = (red1 - red0 + BK - 1) / BK;
+  if (nk <= 0) return;
+  const int ohw = g.OH * g.OW;
+
+  // DMA: piece q = wave + 8 i of a plane covers bytes [1024 q, 1024 q + 1024) of the [32][ROW] image: k-row
+  // kr = (1024 q + 16 lane) / ROW, physical chunk cp inside the row; it holds logical chunk cp ^ ((kr & 3) << 2)
+  int a_kr[RQA], b_kr[RQB];
+  unsigned a_col[RQA], b_col[RQB];
+  STCAT_UNROLL
+  for (int i = 0; i < RQA; ++i) {
+    const int q = wave + 8 * i, byte = q * 1024 + lane * 16, kr = byte / ROWA, cp = (byte % ROWA) / 16;
+    a_kr[i] = q < QA ? kr : -1;
+    a_col[i] = (unsigned)((m0 * 2) + ((cp ^ ((kr & 3) << 2)) * 16));
+  }
+  STCAT_UNROLL
+  for (int i = 0; i < RQB; ++i) {
+    const int q = wave + 8 * i, byte = q * 1024 + lane * 16, kr = byte / ROWB, cp = (byte % ROWB) / 16;
+    b_kr[i] = q < QB ? kr : -1;
+    b_col[i] = (unsigned)((ci0 * 2) + ((cp ^ ((kr & 3) << 2)) * 16));
+  }
+  const stcat_buf_t dAh = stcat_make_buf(p.Ah, p.a_bytes), dAl = stcat_make_buf(p.Al, p.a_bytes);
+  const stcat_buf_t dBh = stcat_make_buf(p.Bh, p.b_bytes), dBl = stcat_make_buf(p.Bl, p.b_bytes);
+  int kl = 0;
+#define STCAT_PLW_STAGE_LOAD(ST)                                                                        \
+  {                                                                                                     \
+    const int mb_ = red0 + kl * BK;                                                                     \
+    char* base_ = smem + (ST) * STAGE + wq * 1024;                                                      \
+    STCAT_UNROLL                                                                                        \
+    for (int i = 0; i < RQA; ++i) {                                                                     \
+      const int m_ = mb_ + a_kr[i];                                                                     \
+      const unsigned vo_ = (a_kr[i] >= 0 && m_ < red1) ? (unsigned)(m_ * p.ldb) * 2u + a_col[i] : STCAT_BUF_OOB; \
+      if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
+        stcat_glds16(dAh, base_ + i * 8192, vo_, 0u);                                                   \
+        stcat_glds16(dAl, base_ + PLANE_A + i * 8192, vo_, 0u);                                         \
+      }                                                                                                 \
+    }                                                                                                   \
+    STCAT_UNROLL                                                                                        \
+    for (int i = 0; i < RQB; ++i) {                                                                     \
+      const int m_ = mb_ + b_kr[i];                                                                     \
+      const int nb_ = stcat_fastdiv(m_, g.mg_ohw, g.sh_ohw), rem_ = m_ - nb_ * ohw;                     \
+      const int oh_ = stcat_fastdiv(rem_, g.mg_ow, g.sh_ow), ow_ = rem_ - oh_ * g.OW;                   \
+      const int h_ = oh_ * g.mul + g.off + kh, w_ = ow_ * g.mul + g.off + kw;                           \
+      const bool ok_ = (b_kr[i] >= 0) & (m_ < red1) & ((unsigned)h_ < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W); \
+      const unsigned vo_ = ok_ ? (unsigned)(((nb_ * g.H + h_) * g.W + w_) * g.ld) * 2u + b_col[i] : STCAT_BUF_OOB; \
+      if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
+        stcat_glds16(dBh, base_ + 2 * PLANE_A + i * 8192, vo_, 0u);                                     \
+        stcat_glds16(dBl, base_ + 2 * PLANE_A + PLANE_B + i * 8192, vo_, 0u);                           \
+      }                                                                                                 \
+    }                                                                                                   \
+    ++kl;                                                                                               \
+  }
+
+  // fragment addressing (transposing reads): lane -> 16-lane group gq = (lane >> 4) & 1: channels 16 gq .. + 15 of its
+  // 32-wide tile, k half hi; inside the group lane pl addresses k-row (pl >> 2), channels 4 (pl & 3) .. + 3 (8 bytes).
+  // k = 16 ks + 8 hi + 4 j + (pl >> 2), j = 0, 1: two reads give the 8 consecutive k of the fragment.  k & 3 = pl >> 2
+  // for every (ks, j), so the swizzle term is a lane constant per tile: tile T of the wave = 64-byte segment
+  // (wave's first segment + T) ^ (pl >> 2).
+  const int pl = lane & 15, gq = (lane >> 4) & 1, kx = pl >> 2;
+  const unsigned ta_lane = (unsigned)((hi * 8 + kx) * ROWA + gq * 32 + (pl & 3) * 8);
+  const unsigned tb_lane = (unsigned)(2 * PLANE_A + (hi * 8 + kx) * ROWB + gq * 32 + (pl & 3) * 8);
+  unsigned ta_seg[TM], tb_seg[TN];
+  STCAT_UNROLL
+  for (int tm = 0; tm < TM; ++tm) ta_seg[tm] = (unsigned)(((wm * TM + tm) ^ kx) << 6);
+  STCAT_UNROLL
+  for (int tn = 0; tn < TN; ++tn) tb_seg[tn] = (unsigned)(((wn * TN + tn) ^ kx) << 6);
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+#define STCAT_PLW_TR8(DST, ADDR, ROW, KS)                                                               \
+  {                                                                                                     \
+    const bf16x4 lo4_ = stcat_lds_tr4(reinterpret_cast<const __bf16*>((ADDR) + ((KS) * 16) * (ROW)));   \
+    const bf16x4 hi4_ = stcat_lds_tr4(reinterpret_cast<const __bf16*>((ADDR) + ((KS) * 16 + 4) * (ROW))); \
+    STCAT_UNROLL                                                                                        \
+    for (int e_ = 0; e_ < 4; ++e_) { DST[e_] = lo4_[e_]; DST[4 + e_] = hi4_[e_]; }                      \
+  }
+#define STCAT_PLW_READ_FRAG(F, SB, KS)                                                                  \
+  STCAT_UNROLL                                                                                          \
+  for (int tn = 0; tn < TN; ++tn) {                                                                     \
+    STCAT_PLW_TR8(F.bh[tn], (SB) + tb_lane + tb_seg[tn], ROWB, KS)                                      \
+    STCAT_PLW_TR8(F.bl[tn], (SB) + tb_lane + tb_seg[tn] + PLANE_B, ROWB, KS)                            \
+  }                                                                                                     \
+  STCAT_UNROLL                                                                                          \
+  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+    STCAT_PLW_TR8(F.ah[tm], (SB) + ta_lane + ta_seg[tm], ROWA, KS)                                      \
+    STCAT_PLW_TR8(F.al[tm], (SB) + ta_lane + ta_seg[tm] + PLANE_A, ROWA, KS)                            \
+  }
+
+  STCAT_PL_ACC_INIT
+  constexpr int NMMA = 3 * TM * TN, NRD = 4 * (TM + TN);
+  constexpr int NDMA = 2 * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  Frag fa, fb;
+  STCAT_PLW_STAGE_LOAD(0)
+  STCAT_PLW_STAGE_LOAD(1)
+  STCAT_WAIT_VM0();
+  STCAT_S_BARRIER();
+  STCAT_SCHED_FENCE();
+  STCAT_PLW_READ_FRAG(fa, smem, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * STAGE;
+    const char* sn = smem + ((kt + 1) & 1) * STAGE;
+    STCAT_PLW_READ_FRAG(fb, sb, 1)
+    STCAT_PL_INTERLEAVE(NMMA, NRD, 0)
+    STCAT_PL_MMA(fa)
+    STCAT_SCHED_FENCE();
+    STCAT_WAIT_VM0_LGKM0();
+    STCAT_S_BARRIER();
+    STCAT_SCHED_FENCE();
+    STCAT_PLW_STAGE_LOAD(kt & 1)
+    STCAT_PLW_READ_FRAG(fa, sn, 0)
+    STCAT_PL_INTERLEAVE(NMMA, NRD, NDMA)
+    STCAT_PL_MMA(fb)
+    STCAT_SCHED_FENCE();
+  }
+#undef STCAT_PLW_STAGE_LOAD
+#undef STCAT_PLW_READ_FRAG
+#undef STCAT_PLW_TR8
+  STCAT_WAIT_VM0_LGKM0();
+  const int l31 = lane & 31;
+  STCAT_UNROLL
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n0 + wn * TN * 32 + tn * 32 + l31;
+    STCAT_UNROLL
+    for (int tm = 0; tm < TM; ++tm) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        atomicAdd(&p.Wf[(long)m * p.ldc + n], acc[tm][tn][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plane producers / consumers outside the GEMMs
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max-pool, NHWC fp32 in (stem output) -> planes out (input of layer1)
+__global__ void __launch_bounds__(256) maxpool3x3s2_pl_kernel(const float* x, __bf16* yh, __bf16* yl, int n, int H, int W,
+                                                             int C, int OH, int OW) {
+  const int c8n = C / 8;
+  const long total = (long)n * OH * OW * c8n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % c8n);
+    const long pix = i / c8n;
+    const int ow = (int)(pix % OW), oh = (int)((pix / OW) % OH), f = (int)(pix / ((long)OW * OH));
+    float m[8];
+    STCAT_UNROLL
+    for (int e = 0; e < 8; ++e) m[e] = STCAT_NEG_INF;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = oh * 2 - 1 + kh;
+      if (hh < 0 || hh >= H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = ow * 2 - 1 + kw;
+        if (ww < 0 || ww >= W) continue;
+        const float* src = x + (((long)f * H + hh) * W + ww) * C + c8 * 8;
+        const float4 a = stcat_ld4(src), b = stcat_ld4(src + 4);
+        m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
+        m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+      }
+    }
+    bf16x8 h8, l8;
+    stcat_split8(m, h8, l8);
+    *reinterpret_cast<bf16x8*>(yh + i * 8) = h8;
+    *reinterpret_cast<bf16x8*>(yl + i * 8) = l8;
+  }
+}
+
+// element-wise plane kernels over n8 groups of 8 elements; channel of group i = (i * 8) % C
+//   mode 0: split      out = x (fp32 -> planes)
+//   mode 1: act_bwd    dz = dy * [y > 0] (dy, y fp32; relu = 0: no mask) -> dz planes (R), g = dz * scale[c] planes (G)
+//   mode 2: scale      G = X(planes) * scale[c]
+//   mode 3: join       f = X(planes) -> fp32
+struct PlEwParams {
+  const float* xf; const float* yf; const float* scale;
+  const __bf16* Xh; const __bf16* Xl;
+  __bf16* Gh; __bf16* Gl; __bf16* Rh; __bf16* Rl;
+  float* of;
+  long n8; int C; int mode; int relu;
+};
+__global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    if (p.mode == 0 || p.mode == 1) {
+      const float4 a = stcat_ld4(p.xf + i * 8), b = stcat_ld4(p.xf + i * 8 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      stcat_join8(p.Xh + i * 8, p.Xl + i * 8, v);
+    }
+    if (p.mode == 3) {
+      stcat_st4(p.of + i * 8, make_float4(v[0], v[1], v[2], v[3]));
+      stcat_st4(p.of + i * 8 + 4, make_float4(v[4], v[5], v[6], v[7]));
+      continue;
+    }
+    if (p.mode == 1 && p.relu) {
+      const float4 a = stcat_ld4(p.yf + i * 8), b = stcat_ld4(p.yf + i * 8 + 4);
+      const float yy[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      STCAT_UNROLL
+      for (int e = 0; e < 8; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
+    }
+    bf16x8 h8, l8;
+    if (p.Rh) {
+      stcat_split8(v, h8, l8);
+      *reinterpret_cast<bf16x8*>(p.Rh + i * 8) = h8;
+      *reinterpret_cast<bf16x8*>(p.Rl + i * 8) = l8;
+    }
+    if (p.Gh) {
+      if (p.scale) {
+        const int c = (int)((i * 8) % p.C);
+        STCAT_UNROLL
+        for (int e = 0; e < 8; ++e) v[e] *= p.scale[c + e];
+      }
+      stcat_split8(v, h8, l8);
+      *reinterpret_cast<bf16x8*>(p.Gh + i * 8) = h8;
+      *reinterpret_cast<bf16x8*>(p.Gl + i * 8) = l8;
+    }
+  }
+}
+
+// Weight planes for MANY conv weights in one launch: entry e describes W fp32 OHWI [Cout][taps][Cin] and writes
+//   fwd planes  Wh/Wl [Cout][taps][Cin]   (B operand of the forward GEMM: row = co),
+//   tr  planes  Th/Tl [taps][Cin][Cout]   (B operand of the data gradient: row = ci inside a tap)  — optional.
+// A block handles a 32 (co) x 32 (ci) patch of one tap.
+struct WplEntry {
+  const float* w;
+  __bf16* wh; __bf16* wl; __bf16* th; __bf16* tl;
+  int Cout, taps, Cin;
+  int blk0, nbx, nby;
+  int pad_;
+};
+__global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry* tab, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WplEntry e = tab[lo];
+  const int rel = blockIdx.x - e.blk0;
+  const int bx = rel % e.nbx, by = (rel / e.nbx) % e.nby, tap = rel / (e.nbx * e.nby);
+  const int ci0 = bx * 32, co0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float x = 0.f;
+    if (co < e.Cout && ci < e.Cin) {
+      const long idx = ((long)co * e.taps + tap) * e.Cin + ci;
+      x = e.w[idx];
+      const __bf16 h = (__bf16)x;
+      e.wh[idx] = h;
+      e.wl[idx] = (__bf16)(x - (float)h);
+    }
+    tile[r][tx] = x;
+  }
+  if (!e.th) return;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < e.Cin && co < e.Cout) {
+      const float x = tile[tx][r];
+      const long idx = ((long)tap * e.Cin + ci) * e.Cout + co;
+      const __bf16 h = (__bf16)x;
+      e.th[idx] = h;
+      e.tl[idx] = (__bf16)(x - (float)h);
+    }
+  }
+}

@@ -9,6 +9,7 @@
 #include "optim.h"
 #include "igemm.h"
 #include "igemm_bs.h"
+#include "igemm_pl.h"
 #include "pointwise.h"
 
 namespace {
@@ -73,7 +74,10 @@ void pick_tile(int M, int N, int& BM, int& BN) {
   }
 }
 
-int g_mma_mode = 0;  // 0: fp32 MFMA (exact), 2: split-bf16 x3, 3: split-bf16 x6   (stcat_set_mma_mode)
+// 0: fp32 MFMA (exact), 2: split-bf16 x3, 3: split-bf16 x6, 4: split-bf16 x3 with the backbone's tensors pre-split into
+// bf16 planes (igemm_pl.h; every other GEMM of the path runs as mode 2)   (stcat_set_mma_mode)
+int g_mma_mode_raw = 0;
+int g_mma_mode = 0;  // what the fp32-tensor kernels see: mode 4 -> 2
 
 #define STCAT_TILE_SWITCH(KERNEL, GRID)                                                        \
   if (BM == 128 && BN == 128) {                                                                \
@@ -282,6 +286,88 @@ int launch_wgrad(IgemmParams p, int rows, int cols, int red, hipStream_t st) {
   return launch_status();
 }
 
+// ---- plane-format GEMMs (igemm_pl.h) ---------------------------------------------------------------------------
+template <class K>
+int pl_prepare(K kernel, int lds_bytes) {
+#ifndef STCAT_EMU
+  static bool done = false;  // per instantiation: opt in to > 64 KB of dynamic LDS once
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+      return fail("plane GEMM: cannot reserve %d bytes of LDS", lds_bytes);
+    done = true;
+  }
+#endif
+  return 0;
+}
+#define STCAT_PL_LAUNCH(KERNEL, BM_, BN_, WM_, WN_, GRID)                                              \
+  {                                                                                                    \
+    constexpr int lds_ = 4 * (BM_ + BN_) * 64;                                                         \
+    if (int rc_ = pl_prepare(KERNEL<BM_, BN_, WM_, WN_>, lds_)) return rc_;                            \
+    STCAT_LAUNCH((KERNEL<BM_, BN_, WM_, WN_>), GRID, dim3(512), lds_, st, p);                          \
+  }
+
+int g_pl_force = -1;  // stcat_debug_force_pl_tile: index into the tile table below, -1 = heuristic
+struct PlTile { int bm, bn; float eff; };
+// relative cost per MAC of each tile shape (bigger wave tiles amortise fragment reads and DMA issue better)
+const PlTile kPlTiles[5] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f}};
+
+int pick_pl_tile(int M, int N) {
+  if (g_pl_force >= 0 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
+  int best = -1;
+  float best_cost = 0.f;
+  for (int i = 0; i < 5; ++i) {
+    const PlTile& tl = kPlTiles[i];
+    if (N % tl.bn != 0) continue;
+    const long tiles = (long)cdiv(M, tl.bm) * (N / tl.bn);
+    const long rounds = (tiles + 255) / 256;  // one 8-wave workgroup per CU
+    const float cost = (float)rounds * tl.bm * tl.bn * tl.eff;
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  return best;
+}
+
+int launch_pl_fwd(const PlParams& p, hipStream_t st) {
+  if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
+  if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
+  if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
+  const int ti = pick_pl_tile(p.M, p.N);
+  if (ti < 0) return fail("plane GEMM: N = %d is not a multiple of 64", p.N);
+  const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
+  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  switch (ti) {
+    case 0: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 256, 2, 4, grid) break;
+    case 1: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 128, 4, 2, grid) break;
+    case 2: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 128, 256, 2, 4, grid) break;
+    case 3: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 128, 128, 2, 4, grid) break;
+    default: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 64, 8, 1, grid) break;
+  }
+  return launch_status();
+}
+
+// rows = Cout, cols = taps * Cin, red = pixels
+int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
+  if (rows % 128 != 0 || p.g.C % 128 != 0) return fail("plane wgrad: need Cout, Cin %% 128 == 0 (%d, %d)", rows, p.g.C);
+  const int BM = (rows % 256 == 0 && g_pl_force != 3) ? 256 : 128;
+  const int BN = (p.g.C % 256 == 0 && g_pl_force != 3 && !(BM == 128 && g_pl_force == 3)) ? 256 : 128;
+  const int tiles = (rows / BM) * (cols / BN);
+  int nsplit = 256 / tiles;                 // one round of one workgroup per CU
+  const int max_split = cdiv(red, 512);     // at least 16 K-tiles per workgroup
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int chunk = cdiv(red, nsplit);
+  chunk = ((chunk + 31) / 32) * 32;
+  nsplit = cdiv(red, chunk);
+  p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk;
+  const dim3 grid(tiles, 1, nsplit);
+  if (BM == 256 && BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 256, 2, 4, grid)
+  else if (BM == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 128, 4, 2, grid)
+  else if (BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 128, 256, 2, 4, grid)
+  else STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 128, 128, 2, 4, grid)
+  return launch_status();
+}
+
+inline unsigned plane_bytes(long elems) { return elems * 2 >= 0x7FFFFFFFl ? 0xFFFFFFFFu : (unsigned)(elems * 2); }
+
 IgemmGeom conv_geom_fwd(int H, int W, int C, int ld, int OH, int OW, int KH, int KW, int stride, int pad) {
   IgemmGeom g;
   g.H = H; g.W = W; g.C = C; g.ld = ld; g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW;
@@ -296,11 +382,13 @@ extern "C" {
 
 int stcat_version(void) { return 100; }
 int stcat_set_mma_mode(int mode) {
-  if (mode != 0 && mode != 2 && mode != 3) return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3) or 3 (bf16x6)");
-  g_mma_mode = mode;
+  if (mode != 0 && mode != 2 && mode != 3 && mode != 4)
+    return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (bf16x3 on bf16 planes)");
+  g_mma_mode_raw = mode;
+  g_mma_mode = mode == 4 ? 2 : mode;
   return 0;
 }
-int stcat_get_mma_mode(void) { return g_mma_mode; }
+int stcat_get_mma_mode(void) { return g_mma_mode_raw; }
 
 int stcat_debug_force_tile(int bm, int bn) {
   const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64) ||
@@ -708,6 +796,124 @@ int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chu
 int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out, int b, int T, void* stream) {
   if (T <= 0 || T > 1024) return fail("temporal_map_argmax: T=%d out of range (1..1024)", T);
   STCAT_LAUNCH(temporal_map_argmax_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, sted, durations, out, T);
+  return launch_status();
+}
+
+// ---- plane-format backbone (mma mode 4): every tensor is a pair of bf16 planes (hi, lo) ------------------------
+int stcat_debug_force_pl_tile(int index) {
+  if (index < -1 || index > 4) return fail("debug_force_pl_tile: index must be -1 .. 4");
+  g_pl_force = index;
+  return 0;
+}
+
+int stcat_pl_conv_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* scale,
+                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf, int n, int H,
+                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+  if (Cin % 32 != 0 || Cout % 64 != 0) return fail("pl_conv_fwd: need Cin %% 32 == 0 and Cout %% 64 == 0 (%d, %d)", Cin, Cout);
+  if (!aligned16(xh) || !aligned16(xl) || !aligned16(wh) || !aligned16(wl)) return fail("pl_conv_fwd: planes must be 16-byte aligned");
+  if (!yh && !yf) return fail("pl_conv_fwd: no output");
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  PlParams p = {};
+  p.Ah = (const __bf16*)xh; p.Al = (const __bf16*)xl; p.Bh = (const __bf16*)wh; p.Bl = (const __bf16*)wl;
+  p.Ch = (__bf16*)yh; p.Cl = (__bf16*)yl; p.Cf = yf; p.scale = scale; p.bias = bias;
+  p.Rh = (const __bf16*)rh; p.Rl = (const __bf16*)rl;
+  p.a_bytes = plane_bytes((long)n * H * W * Cin); p.b_bytes = plane_bytes((long)Cout * KH * KW * Cin);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_fwd: a plane exceeds 2 GB");
+  p.b_tap_stride = (unsigned)Cin;
+  p.M = n * OH * OW; p.N = Cout; p.K = KH * KW * Cin; p.ldb = p.K; p.ldc = Cout; p.ldr = Cout; p.relu = relu;
+  p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
+  return launch_pl_fwd(p, (hipStream_t)stream);
+}
+
+int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const void* tl, const void* addh,
+                        const void* addl, const void* yh, const void* yl, const float* mask_scale, void* dxh, void* dxl,
+                        void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int stride, int pad, void* stream) {
+  if ((dx2h != nullptr) != (dx2_scale != nullptr)) return fail("pl_conv_dgrad: dx2 and dx2_scale go together");
+  if (Cout % 32 != 0 || Cin % 64 != 0) return fail("pl_conv_dgrad: need Cout %% 32 == 0 and Cin %% 64 == 0 (%d, %d)", Cout, Cin);
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  PlParams p = {};
+  p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)th; p.Bl = (const __bf16*)tl;
+  p.Ch = (__bf16*)dxh; p.Cl = (__bf16*)dxl; p.Rh = (const __bf16*)addh; p.Rl = (const __bf16*)addl;
+  p.Yh = (const __bf16*)yh; p.Yl = (const __bf16*)yl; p.mscale = mask_scale;
+  p.C2h = (__bf16*)dx2h; p.C2l = (__bf16*)dx2l; p.c2scale = dx2_scale;
+  p.a_bytes = plane_bytes((long)n * OH * OW * Cout); p.b_bytes = plane_bytes((long)Cout * KH * KW * Cin);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_dgrad: a plane exceeds 2 GB");
+  // transposed weight planes [tap][Cin][Cout]: row n = ci (stride Cout), tap stride Cin * Cout
+  p.ldb = Cout; p.b_tap_stride = (unsigned)((long)Cin * Cout);
+  p.M = n * H * W; p.N = Cin; p.K = KH * KW * Cout; p.ldc = Cin; p.ldr = Cin; p.relu = 0;
+  IgemmGeom q;
+  q.H = OH; q.W = OW; q.C = Cout; q.ld = Cout; q.OH = H; q.OW = W; q.KH = KH; q.KW = KW;
+  q.mul = 1; q.off = pad; q.sgn = -1; q.div = stride;
+  stcat_fastdiv_magic(W, &q.mg_ow, &q.sh_ow);
+  stcat_fastdiv_magic(H * W, &q.mg_ohw, &q.sh_ohw);
+  p.g = q;
+  return launch_pl_fwd(p, (hipStream_t)stream);
+}
+
+int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, int n, int H, int W,
+                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  PlParams p = {};
+  p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)xh; p.Bl = (const __bf16*)xl;
+  p.Wf = dw; p.ldb = Cout; p.ldc = KH * KW * Cin;
+  p.a_bytes = plane_bytes((long)n * OH * OW * Cout); p.b_bytes = plane_bytes((long)n * H * W * Cin);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_wgrad: a plane exceeds 2 GB");
+  p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
+  return launch_pl_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
+}
+
+int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int W, int C, void* stream) {
+  if (C % 8 != 0 || !aligned16(x) || !aligned16(yh) || !aligned16(yl)) return fail("pl_maxpool: C %% 8 != 0 or unaligned");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long total = (long)n * OH * OW * (C / 8);
+  STCAT_LAUNCH(maxpool3x3s2_pl_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+               (__bf16*)yh, (__bf16*)yl, n, H, W, C, OH, OW);
+  return launch_status();
+}
+
+static int pl_ew(PlEwParams p, long n, void* stream) {
+  if (n <= 0 || n % 8 != 0) return fail("plane element-wise: n = %ld must be a positive multiple of 8", n);
+  p.n8 = n / 8;
+  STCAT_LAUNCH(planes_ew_kernel, dim3(grid_for(p.n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+int stcat_pl_split(const float* x, void* h, void* l, long n, void* stream) {
+  PlEwParams p = {};
+  p.mode = 0; p.xf = x; p.Rh = (__bf16*)h; p.Rl = (__bf16*)l; p.C = 8;
+  return pl_ew(p, n, stream);
+}
+
+int stcat_pl_join(const void* h, const void* l, float* out, long n, void* stream) {
+  PlEwParams p = {};
+  p.mode = 3; p.Xh = (const __bf16*)h; p.Xl = (const __bf16*)l; p.of = out; p.C = 8;
+  return pl_ew(p, n, stream);
+}
+
+int stcat_pl_act_bwd(const float* dy, const float* y, const float* scale, void* gh, void* gl, void* rh, void* rl, long n,
+                     int C, int relu, void* stream) {
+  if (C % 8 != 0) return fail("pl_act_bwd: C %% 8 != 0");
+  PlEwParams p = {};
+  p.mode = 1; p.xf = dy; p.yf = y; p.scale = scale; p.Gh = (__bf16*)gh; p.Gl = (__bf16*)gl; p.Rh = (__bf16*)rh;
+  p.Rl = (__bf16*)rl; p.C = C; p.relu = relu;
+  return pl_ew(p, n, stream);
+}
+
+int stcat_pl_scale(const void* xh, const void* xl, const float* scale, void* gh, void* gl, long n, int C, void* stream) {
+  if (C % 8 != 0) return fail("pl_scale: C %% 8 != 0");
+  PlEwParams p = {};
+  p.mode = 2; p.Xh = (const __bf16*)xh; p.Xl = (const __bf16*)xl; p.scale = scale; p.Gh = (__bf16*)gh; p.Gl = (__bf16*)gl;
+  p.C = C;
+  return pl_ew(p, n, stream);
+}
+
+int stcat_weight_planes_entry_bytes(void) { return (int)sizeof(WplEntry); }
+
+int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream) {
+  if (n_entries <= 0 || total_blocks <= 0) return fail("weight_planes_multi: empty table");
+  STCAT_LAUNCH(weight_planes_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WplEntry*)table,
+               n_entries);
   return launch_status();
 }
 

@@ -55,6 +55,58 @@ static __device__ __forceinline__ float4 stcat_buf_ld4(stcat_buf_t b, unsigned v
 }
 #endif
 
+// ---- LDS-DMA staging and hand-placed synchronisation of the plane-format GEMM (igemm_pl.h) ----------------------
+// stcat_glds16: every lane moves 16 bytes HBM -> LDS without touching a VGPR: source = descriptor base + voff + soff
+// (bounds-checked: out of range = ZEROS written, measured on gfx950: profiles/r02_probe_lds_dma_tr.log), destination =
+// wave-uniform LDS address + lane * 16.  The transfer is counted by vmcnt; nothing orders a later ds_read behind it
+// except the issuing wave's s_waitcnt vmcnt + a barrier (MI355X_MICROARCH.md §Two waves per SIMD, item 7).
+// stcat_lds_tr4: ds_read_b64_tr_b16 — the 16 lanes of a group read a [4][16] block of 16-bit elements (lane p supplies
+// the address of row p >> 2, columns 4 (p & 3) .. +3) and lane i receives column i: the transpose a k-major operand
+// needs to become an MFMA fragment (same measurement).
+#ifdef STCAT_EMU
+static inline void stcat_glds16(stcat_buf_t b, char* lds_wave_base, unsigned voff, unsigned soff) {
+  const unsigned long off = (unsigned long)voff + soff;
+  char* dst = lds_wave_base + emu::lane() * 16;
+  if (voff >= STCAT_BUF_OOB || off + 16 > b.bytes) memset(dst, 0, 16);
+  else memcpy(dst, b.base + off, 16);
+}
+static inline bf16x4 stcat_lds_tr4(const __bf16* addr) {
+  emu::WaveState& w = emu::wave();
+  const int l = emu::lane();
+  w.xp[l] = addr;
+  emu::wave_sync();
+  bf16x4 r;
+  const int g = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; ++j) r[j] = static_cast<const __bf16*>(w.xp[g + j * 4 + (i >> 2)])[i & 3];
+  emu::wave_sync();
+  return r;
+}
+#define STCAT_WAIT_VM0_LGKM0() ((void)0)
+#define STCAT_WAIT_VM0() ((void)0)
+#define STCAT_WAIT_VM(n) ((void)0)
+#define STCAT_S_BARRIER() __syncthreads()
+#define STCAT_SCHED_FENCE() ((void)0)
+#define STCAT_WAVE_LDS_FENCE() emu::wave_sync()
+#define STCAT_READFIRSTLANE(x) (x)
+#else
+static __device__ __forceinline__ void stcat_glds16(stcat_buf_t b, char* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff,
+                                           (int)soff, 0, 0);
+}
+static __device__ __forceinline__ bf16x4 stcat_lds_tr4(const __bf16* addr) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)addr);
+  return __builtin_bit_cast(bf16x4, v);
+}
+#define STCAT_WAIT_VM0_LGKM0() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define STCAT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STCAT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define STCAT_S_BARRIER() __builtin_amdgcn_s_barrier()
+#define STCAT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define STCAT_WAVE_LDS_FENCE() ((void)0)  /* DS operations of one wave execute in order */
+#define STCAT_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 #define STCAT_WAVE 64
 #define STCAT_NEG_INF (-__builtin_inff())
 

@@ -908,3 +908,166 @@ def temporal_map_argmax(pred_sted: torch.Tensor, durations: Sequence[int]) -> to
     out = torch.empty(b, 2, dtype=torch.int32, device=sted.device)
     L.call("stcat_temporal_map_argmax", sted.data_ptr(), dur.data_ptr(), out.data_ptr(), b, T, L.stream_of(sted))
     return out
+
+
+# ------------------------------------------------------------------------------------
+# plane-format backbone (mma mode "bf16x3p", csrc/igemm_pl.h): x = h + l as two bf16 planes
+# ------------------------------------------------------------------------------------
+_bf16 = torch.bfloat16
+WEIGHT_EPOCH = 0  # bumped by the fused optimizer (it updates parameters through raw pointers: no torch version bump)
+
+
+class Planes:
+    """A tensor held as two bf16 planes (hi = bf16(x), lo = bf16(x - hi)) in ONE allocation [2, *shape]."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dtype == _bf16 and t.shape[0] == 2 and t.is_contiguous()
+        self.t = t
+
+    @staticmethod
+    def empty(like: torch.Tensor, *shape) -> "Planes":
+        return Planes(torch.empty((2, *shape), device=like.device, dtype=_bf16))
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape[1:])
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def numel(self) -> int:
+        return self.t[0].numel()
+
+    @property
+    def h(self) -> int:
+        return self.t.data_ptr()
+
+    @property
+    def l(self) -> int:
+        return self.t.data_ptr() + self.t[0].numel() * 2
+
+
+def _pl(p: Optional[Planes]):
+    return (None, None) if p is None else (p.h, p.l)
+
+
+def pl_split(x: torch.Tensor) -> Planes:
+    x = _c(x)
+    _chk(x)
+    out = Planes.empty(x, *x.shape)
+    L.call("stcat_pl_split", x.data_ptr(), out.h, out.l, x.numel(), L.stream_of(x))
+    return out
+
+
+def pl_join(p: Planes) -> torch.Tensor:
+    out = torch.empty(p.shape, device=p.device, dtype=_f32)
+    L.call("stcat_pl_join", p.h, p.l, out.data_ptr(), p.numel(), L.stream_of(out))
+    return out
+
+
+def pl_maxpool_raw(x: torch.Tensor) -> Planes:
+    n, H, W, C = x.shape
+    OH, OW = conv_out_hw(H, W, 3, 2, 1)
+    y = Planes.empty(x, n, OH, OW, C)
+    L.call("stcat_pl_maxpool3x3s2", x.data_ptr(), y.h, y.l, n, H, W, C, L.stream_of(x))
+    return y
+
+
+def pl_conv_fwd_raw(x: Planes, w: Planes, scale, bias, res: Optional[Planes], stride, pad, relu, planes_out=True,
+                    f32_out=False):
+    """w: planes of the OHWI weight [Cout,KH,KW,Cin].  Returns (y planes | None, y fp32 | None)."""
+    n, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH, OW = conv_out_hw(H, W, KH, stride, pad)
+    yp = Planes.empty(x.t, n, OH, OW, Cout) if planes_out else None
+    yf = torch.empty(n, OH, OW, Cout, device=x.device, dtype=_f32) if f32_out else None
+    L.call("stcat_pl_conv_fwd", x.h, x.l, w.h, w.l, L._ptr(scale), L._ptr(bias), *_pl(res), *_pl(yp), L._ptr(yf),
+           n, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), L.stream_of(x.t))
+    return yp, yf
+
+
+def pl_conv_dgrad_raw(g: Planes, wt: Planes, in_shape, k, stride, pad, add: Optional[Planes] = None,
+                      out: Optional[Planes] = None, mask_y: Optional[Planes] = None, mask_scale=None, scale2=None):
+    """wt: TRANSPOSED weight planes [taps, Cin, Cout].  Semantics of conv_dgrad_raw on planes."""
+    n, H, W, Cin = in_shape
+    Cout = g.shape[-1]
+    dx = Planes.empty(g.t, n, H, W, Cin) if out is None else out
+    dx2 = Planes.empty(g.t, n, H, W, Cin) if scale2 is not None else None
+    L.call("stcat_pl_conv_dgrad", g.h, g.l, wt.h, wt.l, *_pl(add), *_pl(mask_y), L._ptr(mask_scale), dx.h, dx.l,
+           *_pl(dx2), L._ptr(scale2), n, H, W, Cin, Cout, k, k, stride, pad, L.stream_of(g.t))
+    return dx if scale2 is None else (dx, dx2)
+
+
+def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad) -> torch.Tensor:
+    n, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_shape_ohwi
+    dw = _zeros(g.t, Cout, KH, KW, Cin)
+    L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), n, H, W, Cin, Cout, KH, KW, stride, pad,
+           L.stream_of(g.t))
+    return dw
+
+
+def pl_act_bwd_raw(dy: torch.Tensor, y: Optional[torch.Tensor], scale, want_g=True, want_res=False, relu=True):
+    dy = _c(dy)
+    C = dy.shape[-1]
+    G = Planes.empty(dy, *dy.shape) if want_g else None
+    R = Planes.empty(dy, *dy.shape) if want_res else None
+    L.call("stcat_pl_act_bwd", dy.data_ptr(), L._ptr(y), L._ptr(scale), *_pl(G), *_pl(R), dy.numel(), C, int(relu),
+           L.stream_of(dy))
+    return G, R
+
+
+def pl_scale_raw(x: Planes, scale: torch.Tensor) -> Planes:
+    out = Planes.empty(x.t, *x.shape)
+    L.call("stcat_pl_scale", x.h, x.l, scale.data_ptr(), out.h, out.l, x.numel(), x.shape[-1], L.stream_of(x.t))
+    return out
+
+
+class WeightPlanes:
+    """bf16 hi/lo planes of a fixed list of conv weights, refreshed with ONE launch: forward planes [Cout,KH,KW,Cin]
+    and (when `transposed`) the data-gradient operand [taps,Cin,Cout].  Buffers and the device table are persistent;
+    a refresh is skipped when no weight changed since the last one (tensor versions + the optimizer epoch)."""
+
+    def __init__(self):
+        self.key = None
+        self.state = None
+        self.table = None
+        self.fwd = {}
+        self.tr = {}
+        self.total = 0
+        self.n = 0
+
+    def refresh(self, weights, transposed: bool):
+        """weights: list of OHWI fp32 tensors; returns ({ptr: Planes fwd}, {ptr: Planes transposed})"""
+        import numpy as np
+        key = (tuple(w.data_ptr() for w in weights), bool(transposed) or bool(self.tr))
+        if key != self.key:
+            want_tr = key[1]
+            dt = np.dtype([("w", "<u8"), ("wh", "<u8"), ("wl", "<u8"), ("th", "<u8"), ("tl", "<u8"), ("Cout", "<i4"),
+                           ("taps", "<i4"), ("Cin", "<i4"), ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4"),
+                           ("pad", "<i4"), ("pad2", "<i4")])
+            assert dt.itemsize == L.load().stcat_weight_planes_entry_bytes(), dt.itemsize
+            tab = np.zeros(len(weights), dtype=dt)
+            self.fwd, self.tr, blk = {}, {}, 0
+            for i, w in enumerate(weights):
+                Cout, KH, KW, Cin = w.shape
+                taps = KH * KW
+                wp = Planes.empty(w, Cout, KH, KW, Cin)
+                self.fwd[w.data_ptr()] = wp
+                th = tl = 0
+                if want_tr:
+                    tp = Planes.empty(w, taps, Cin, Cout)
+                    self.tr[w.data_ptr()] = tp
+                    th, tl = tp.h, tp.l
+                nbx, nby = (Cin + 31) // 32, (Cout + 31) // 32
+                tab[i] = (w.data_ptr(), wp.h, wp.l, th, tl, Cout, taps, Cin, blk, nbx, nby, 0, 0)
+                blk += nbx * nby * taps
+            self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(weights[0].device)
+            self.total, self.key, self.n, self.state = blk, key, len(weights), None
+        state = (WEIGHT_EPOCH, tuple(w._version for w in weights))
+        if state != self.state:
+            L.call("stcat_weight_planes_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
+            self.state = state
+        return self.fwd, self.tr

@@ -155,6 +155,8 @@ class AdamW:
         t = self._table
         stream = L.stream_of(any_p)
         self.step_count += 1
+        from . import ops
+        ops.WEIGHT_EPOCH += 1  # parameters change below through raw pointers: derived copies (weight planes) are stale
         sq = None
         if max_grad_norm and max_grad_norm > 0:
             L.call("stcat_grad_sqnorm", t.table.data_ptr(), t.chunk_tensor.data_ptr(), t.chunk_off.data_ptr(),

@@ -58,6 +58,7 @@ struct WaveState {
   float xa[64], xb[64];
   int xi[64];
   float xa8[64][8], xb8[64][8];
+  const void* xp[64];
 };
 struct BlockCtx {
   std::vector<Fiber> fibers;

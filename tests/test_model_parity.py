@@ -287,14 +287,24 @@ def test_gpu_c1_forward_backward(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6", "bf16x3p"])
 def test_gpu_c1_split_bf16_modes(mma):
     """The split-bf16 GEMM modes must meet the same bars as the fp32-MFMA mode."""
     dev = use_hip()
     T, res, L = synth.CONFIGS["C1"]
     g64 = _run_oracle(T, res, L, dtype=torch.float64)[4]
     _compare(_run_hip(dev, T, res, L, mma=mma), _run_oracle(T, res, L), g64=g64,
-             grad_caps=GRAD_CAPS_16BIT if mma == "bf16x3" else None)
+             grad_caps=GRAD_CAPS_16BIT if mma in ("bf16x3", "bf16x3p") else None)
+
+
+def test_emu_tiny_clip_bf16x3_planes():
+    """mma mode bf16x3p: the plane-format backbone (LDS-DMA staged GEMMs, transposing-read weight gradient) end to end."""
+    dev = use_emu()
+    g64 = _run_oracle(2, 64, 3, dtype=torch.float64)[4]
+    # (tiny clip = wiring check: layer3 is a 4x4 map of 2 frames, one flipped ReLU kink moves a conv gradient by
+    # several 1e-2; the residual stream also carries 16 instead of 24 significand bits here)
+    _compare(_run_hip(dev, 2, 64, 3, mma="bf16x3p"), _run_oracle(2, 64, 3), g64=g64,
+             grad_caps={k: min(16 * v, 0.1) for k, v in GRAD_CAPS_16BIT.items()})
 
 
 def test_emu_tiny_clip_bf16x3():

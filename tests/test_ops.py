@@ -151,6 +151,93 @@ def _conv(dev, big):
         _conv_case(dev, 8, 56, 56, 256, 128, 1, 1, 0, relu=True, res=False)
 
 
+# ---------------------------------------------------------------------------------------
+# plane-format conv family (mma mode "bf16x3p", csrc/igemm_pl.h): operands pre-split into bf16 hi/lo planes
+# ---------------------------------------------------------------------------------------
+def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, wgrad=True):
+    x = rnd(n, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    scale, bias = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    r = rnd(*ref.shape, seed=6) if res else None
+    if res:
+        ref = ref + r
+    gy = rnd(*ref.shape, seed=5)
+    if relu:
+        gy = gy * (ref.detach().abs() > 1e-3)
+        ref = F.relu(ref)
+    ref.backward(gy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    sd, bd = scale.to(dev), bias.to(dev)
+    xp = ops.pl_split(xd)
+    close(ops.pl_join(xp), xd, 2e-5, "split/join round trip")  # hi + lo carries 16 significand bits
+    rp = ops.pl_split(r.permute(0, 2, 3, 1).contiguous().to(dev)) if res else None
+    cache = ops.WeightPlanes()
+    wp, wt = cache.refresh([wd], transposed=True)
+    wp, wt = wp[wd.data_ptr()], wt[wd.data_ptr()]
+    close(ops.pl_join(wp), wd, 2e-5, "weight planes")
+    close(ops.pl_join(wt), wd.view(Cout, k * k, Cin).permute(1, 2, 0), 2e-5, "transposed weight planes")
+    L.call("stcat_debug_force_pl_tile", tile)
+    try:
+        yp, yf = ops.pl_conv_fwd_raw(xp, wp, sd, bd, rp, stride, pad, relu, planes_out=True, f32_out=True)
+        gyd = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+        G, dres = ops.pl_act_bwd_raw(gyd, yf, sd, want_g=True, want_res=True, relu=relu)
+        dx = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad)
+        ymask = torch.randn_like(xd)
+        msc = torch.rand(xd.shape[-1], device=dev) + 0.5
+        dx3 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, mask_y=ops.pl_split(ymask), mask_scale=msc)
+        dx4, dx5 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, add=dx, mask_y=ops.pl_split(ymask), scale2=msc)
+        dw = ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad) if wgrad else None
+        gs = ops.pl_scale_raw(G, msc[:1].expand(Cout).contiguous())
+    finally:
+        L.call("stcat_debug_force_pl_tile", -1)
+    tag = f"plane conv {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
+    close(yf.permute(0, 3, 1, 2), ref, TOL, tag + " fwd (fp32 out)")
+    close(ops.pl_join(yp), yf, 2e-5, tag + " fwd (planes out)")
+    close(ops.pl_join(dx).permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
+    ref3 = xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0) * msc.cpu()
+    close(ops.pl_join(dx3), ref3, TOL, tag + " dgrad+fused relu/bn backward")
+    ref4 = 2 * xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0)
+    close(ops.pl_join(dx4), ref4, TOL, tag + " dgrad boundary dz")
+    close(ops.pl_join(dx5), ref4 * msc.cpu(), TOL, tag + " dgrad boundary dz*scale")
+    close(ops.pl_join(gs), ops.pl_join(G).cpu() * msc[:1].cpu(), 2e-5, tag + " plane scale")
+    if wgrad:
+        close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
+    if res:
+        mask = (ref > 0).float() if relu else torch.ones_like(ref)
+        close(ops.pl_join(dres).permute(0, 3, 1, 2), gy * mask, 2e-5, tag + " dres")
+
+
+@both
+def _pl_conv(dev, big):
+    # every tile shape of the table (0: 256x256, 1: 256x128, 2: 128x256, 3: 128x128, 4: 256x64); ragged row tails;
+    # stride 2 (forward lattice + transposed-conv lattice); weight gradient needs Cin, Cout % 128 == 0
+    _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=4, wgrad=False)
+    _pl_conv_case(dev, 1, 8, 8, 64, 128, 3, 2, 1, relu=True, res=False, tile=3, wgrad=False)
+    _pl_conv_case(dev, 1, 9, 7, 128, 128, 1, 2, 0, relu=False, res=False, tile=1)
+    _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2)
+    _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0)
+    if big:
+        _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
+        _pl_conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False)
+        _pl_conv_case(dev, 4, 28, 28, 512, 1024, 1, 2, 0, relu=False, res=False)
+        _pl_conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True)
+        _pl_conv_case(dev, 8, 56, 56, 256, 128, 1, 1, 0, relu=True, res=False)
+        _pl_conv_case(dev, 8, 56, 56, 64, 64, 3, 1, 1, relu=True, res=False, wgrad=False)
+        _pl_conv_case(dev, 16, 14, 14, 512, 512, 3, 1, 1, relu=True, res=False)
+
+
+@both
+def _pl_maxpool(dev, big):
+    n, H, C = (2, 10, 64) if not big else (4, 112, 64)
+    x = rnd(n, C, H, H, seed=1)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    y = ops.pl_maxpool_raw(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    close(ops.pl_join(y).permute(0, 3, 1, 2), ref, 2e-5, "plane maxpool")
+
+
 @both
 def _stem_pool(dev, big):
     n, H = (2, 20) if not big else (4, 224)

@@ -23,6 +23,8 @@ SHAPES = [
     ("l3.conv1 1x1 1024>256", 64, 28, 28, 1024, 256, 1, 1, 0),
     ("l4.conv2 3x3 512", 64, 14, 14, 512, 512, 3, 1, 1),
     ("l4.conv3 1x1 512>2048", 64, 14, 14, 512, 2048, 1, 1, 0),
+    ("l4.conv1 1x1 2048>512", 64, 14, 14, 2048, 512, 1, 1, 0),
+    ("l3.0.conv2 3x3/2 256", 64, 56, 56, 256, 256, 3, 2, 1),
     ("enc.ffn1 256>2048", 1, 1, 13248, 256, 2048, 1, 1, 0),
     ("enc.qk 256>512", 1, 1, 13248, 256, 512, 1, 1, 0),
     ("enc.out 256>256", 1, 1, 13248, 256, 256, 1, 1, 0),
@@ -49,6 +51,7 @@ def main():
     ap.add_argument("--tile", default="")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--pl-tile", type=int, default=-1, help="force the plane-GEMM tile index (bf16x3p)")
     args = ap.parse_args()
     L.load(os.environ.get("STCAT_LIB_OVERRIDE", L.LIB_PATH))  # experiment builds only
     L.set_mma_mode(args.mma)
@@ -60,6 +63,40 @@ def main():
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     for name, n, H, W, Cin, Cout, k, stride, pad in SHAPES:
         if args.only and args.only not in name:
+            continue
+        if args.mma == "bf16x3p":
+            if n == 1:
+                continue  # the Linear shapes stay on the fp32-tensor kernels
+            if args.pl_tile >= 0:
+                L.call("stcat_debug_force_pl_tile", args.pl_tile)
+            x = torch.randn(n, H, W, Cin, device=dev)
+            w = torch.randn(Cout, k, k, Cin, device=dev) * (Cin * k * k) ** -0.5
+            sc, bi = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+            xp = ops.pl_split(x)
+            cache = ops.WeightPlanes()
+            wp, wt = cache.refresh([w], transposed=True)
+            wp, wt = wp[w.data_ptr()], wt[w.data_ptr()]
+            yp, _ = ops.pl_conv_fwd_raw(xp, wp, sc, bi, None, stride, pad, True)
+            gp = ops.pl_split(torch.randn(*yp.shape, device=dev))
+            flop = 2.0 * yp.numel() * k * k * Cin
+            dxo = ops.Planes.empty(x, *x.shape)
+            t_f = timeit(lambda: ops.pl_conv_fwd_raw(xp, wp, sc, bi, None, stride, pad, True))
+            t_d = timeit(lambda: ops.pl_conv_dgrad_raw(gp, wt, x.shape, k, stride, pad, out=dxo, mask_y=xp, mask_scale=None))
+            t_w = float("nan")
+            if Cin % 128 == 0 and Cout % 128 == 0:
+                dw = torch.zeros_like(w)
+
+                def wgp():
+                    L.call("stcat_pl_conv_wgrad", gp.h, gp.l, xp.h, xp.l, dw.data_ptr(), n, H, W, Cin, Cout, k, k, stride,
+                           pad, L.stream_of(x))
+                t_w = timeit(wgp)
+            for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
+                if t == t:
+                    tot[key][0] += flop
+                    tot[key][1] += t
+            print(f"{name:26s} M={n*H*W:7d} N={Cout:4d} K={k*k*Cin:5d}  fwd {flop/t_f/1e9:7.1f}  dgrad {flop/t_d/1e9:7.1f}  "
+                  f"wgrad {flop/t_w/1e9:7.1f} TF   ({t_f:.3f} / {t_d:.3f} / {t_w:.3f} ms)")
+            del x, w, xp, yp, gp, dxo
             continue
         x = torch.randn(n, H, W, Cin, device=dev)
         w = torch.randn(Cout, k, k, Cin, device=dev) * (Cin * k * k) ** -0.5
