@@ -86,15 +86,20 @@ int stcat_act_bwd(const float* dy, const float* y, const float* scale, float* G,
  * plane.  The split is done once by the producing kernel's epilogue, so the GEMM main loop moves operands
  * HBM -> LDS by LDS-DMA and issues nothing but fragment reads and MFMAs (stcat_amd/csrc/igemm_pl.h).
  * Products are hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (= mode 2 arithmetic). */
-/* y = relu?(scale*conv(x,w) + bias + res): planes in, planes (yh, yl) and/or fp32 (yf) out; res planes optional */
+/* y = relu?(scale*conv(x,w) + bias + res): planes in, planes (yh, yl) and/or fp32 (yf) out; res planes optional.
+ * ymask (optional, [n*OH*OW][Cout / 8] bytes): bit e of byte j of a row = (y[8 j + e] > 0) — the ReLU mask the
+ * backward pass needs, at 1/32 of the bytes of re-reading y */
 int stcat_pl_conv_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* scale,
-                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf, int n, int H,
-                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream);
+                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf,
+                      unsigned char* ymask, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                      int relu, void* stream);
 /* dx = conv_transpose(g, w) (+ add), then the fused ReLU + FrozenBN backward of the layer below (y planes,
- * mask_scale) and the optional second output dx2 = dx * dx2_scale — semantics of stcat_conv_dgrad.  th / tl are the
- * TRANSPOSED weight planes [taps][Cin][Cout] written by stcat_weight_planes_multi. */
+ * mask_scale) and the optional second output dx2 = dx * dx2_scale — semantics of stcat_conv_dgrad.  The mask comes
+ * either as the y planes (yh, yl) or as the bit mask the forward pass wrote (ybits, see stcat_pl_conv_fwd).  th / tl
+ * are the TRANSPOSED weight planes [taps][Cin][Cout] written by stcat_weight_planes_multi. */
 int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const void* tl, const void* addh,
-                        const void* addl, const void* yh, const void* yl, const float* mask_scale, void* dxh, void* dxl,
+                        const void* addl, const void* yh, const void* yl, const unsigned char* ybits,
+                        const float* mask_scale, void* dxh, void* dxl,
                         void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, void* stream);
 /* dw (fp32 OHWI, caller-zeroed) += sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0 */
@@ -120,6 +125,9 @@ int stcat_weight_planes_entry_bytes(void);
 int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream);
 /* tuning/test hook: force the plane-GEMM tile (0: 256x256, 1: 256x128, 2: 128x256, 3: 128x128, 4: 256x64; -1 = heuristic) */
 int stcat_debug_force_pl_tile(int index);
+/* timing experiments (results are WRONG when set): 1 = weight gradient without its atomics, 2 = forward / data-gradient
+ * epilogue without global memory traffic; 0 = off */
+int stcat_debug_pl_flags(int flags);
 
 /* ---- position embeddings ------------------------------------------------------------------------ */
 /* PositionEmbeddingSine(128, normalize=True) (vision_model/position_encoding.py:70-94):

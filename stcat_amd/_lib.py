@@ -53,8 +53,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_ema_update": "pppiifs",
     "stcat_optim_table_entry_bytes": "",
     "stcat_temporal_map_argmax": "pppiis",
-    "stcat_pl_conv_fwd": "ppppppppppp" + "iiiiiiiiii" + "s",
-    "stcat_pl_conv_dgrad": "pppppppppppppp" + "iiiiiiiii" + "s",
+    "stcat_pl_conv_fwd": "pppppppppppp" + "iiiiiiiiii" + "s",
+    "stcat_pl_conv_dgrad": "ppppppppppppppp" + "iiiiiiiii" + "s",
     "stcat_pl_conv_wgrad": "ppppp" + "iiiiiiiii" + "s",
     "stcat_pl_maxpool3x3s2": "pppiiiis",
     "stcat_pl_split": "pppls",
@@ -64,6 +64,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_weight_planes_entry_bytes": "",
     "stcat_weight_planes_multi": "piis",
     "stcat_debug_force_pl_tile": "i",
+    "stcat_debug_pl_flags": "i",
     "stcat_debug_force_tile": "ii",
     "stcat_debug_streamk": "i",
     "stcat_set_mma_mode": "i",

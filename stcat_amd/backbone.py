@@ -201,8 +201,12 @@ class _BackboneFnPl(Function):
             s1, b1 = blk.bn1.folded()
             s2, b2 = blk.bn2.folded()
             s3, b3 = blk.bn3.folded()
-            o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True)
-            o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True)
+            # ReLU bit masks for the backward pass: of o1 / o2 in trainable blocks, and of a block output whose
+            # consumer (the next block) is trainable
+            tr = need_bwd and blk.conv1.weight.requires_grad
+            tr_next = need_bwd and not last and blocks[bi + 1][1].conv1.weight.requires_grad
+            o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True, want_mask=tr)
+            o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True, want_mask=tr)
             wd = sd = None
             if blk.downsample is not None:
                 wd = _ohwi(blk.downsample[0].weight)
@@ -210,7 +214,8 @@ class _BackboneFnPl(Function):
                 idt, _ = ops.pl_conv_fwd_raw(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
             else:
                 idt = x
-            y, yf = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last)
+            y, yf = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last,
+                                        want_mask=tr_next)
             if need_bwd and blk.conv1.weight.requires_grad:
                 tape.append((blk, x, o1, o2, yf if last else y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
             x = y
@@ -224,21 +229,32 @@ class _BackboneFnPl(Function):
         grads = {}
         tape, wt = ctx.tape, ctx.wt
         _wt = lambda w: wt[w.data_ptr()]  # noqa: E731
+        # Weight gradients leave the critical path: they only feed the optimizer, so they run on a second stream
+        # behind the data-gradient chain.  The plane GEMMs own a whole CU per workgroup and most launches fill the
+        # chip unevenly (layer3: 196-224 workgroups on 256 CUs, a partial last round elsewhere): the weight-gradient
+        # workgroups run on the CUs the data-gradient launch leaves idle.
+        wg = ops.WgradStream(dy)
+
+        def wgrad(key, g, xin, wshape, stride, pad):
+            with wg:
+                grads[key] = ops.pl_conv_wgrad_raw(g, xin, wshape, stride, pad)
+            wg.keep(g, xin)
+
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
         # top of the stack (y is the fp32 layer4 output): dz = dy * [y > 0], g3 = dz * scale3 — both as planes
         g3, dz = ops.pl_act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
         for idx in range(len(tape) - 1, -1, -1):
             blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd) = tape[idx]
             need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
-            grads[id(blk.conv3.weight)] = ops.pl_conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
+            wgrad(id(blk.conv3.weight), g3, o2, w3.shape, 1, 0)
             g2 = ops.pl_conv_dgrad_raw(g3, _wt(w3), o2.shape, 1, 1, 0, mask_y=o2, mask_scale=s2)
-            grads[id(blk.conv2.weight)] = ops.pl_conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
+            wgrad(id(blk.conv2.weight), g2, o1, w2.shape, blk.stride, 1)
             g1 = ops.pl_conv_dgrad_raw(g2, _wt(w2), o1.shape, 3, blk.stride, 1, mask_y=o1, mask_scale=s1)
-            grads[id(blk.conv1.weight)] = ops.pl_conv_wgrad_raw(g1, x, w1.shape, 1, 0)
+            wgrad(id(blk.conv1.weight), g1, x, w1.shape, 1, 0)
             gd = None
             if wd is not None:
                 gd = ops.pl_scale_raw(dz, sd)  # dz * scale_downsample
-                grads[id(blk.downsample[0].weight)] = ops.pl_conv_wgrad_raw(gd, x, wd.shape, blk.stride, 0)
+                wgrad(id(blk.downsample[0].weight), gd, x, wd.shape, blk.stride, 0)
             if not need_dx:
                 break
             s3_below = tape[idx - 1][6][2]
@@ -248,6 +264,7 @@ class _BackboneFnPl(Function):
                                                scale2=s3_below)
             else:
                 dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=dz, mask_y=x, scale2=s3_below)
+        wg.join(*grads.values())
         out = []
         for w in ctx.body.parameters():
             g = grads.get(id(w))

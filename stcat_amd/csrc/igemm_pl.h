@@ -37,6 +37,9 @@ struct PlParams {
   const float* scale; const float* bias;
   const __bf16* Rh; const __bf16* Rl;   // residual planes [M][ldr] or null
   const __bf16* Yh; const __bf16* Yl;   // dgrad: planes of y [M][ldc] (output of the layer below): result zeroed where y <= 0 ...
+  const unsigned char* Mi;              // the same mask as ONE BIT per element [M][ldc / 8] (bit e of byte j = y[m][8 j + e] > 0),
+                                        // written by the forward epilogue of the layer below (Mo): 1/32 of the plane bytes
+  unsigned char* Mo;                    // forward: optional bit mask of the output (y > 0) for the backward pass
   const float* mscale;                  // ... and multiplied by that layer's FrozenBN scale (or null)
   __bf16* C2h; __bf16* C2l; const float* c2scale;  // optional second output C * c2scale[n]
   int M, N, K, ldb, ldc, ldr, relu;
@@ -44,6 +47,8 @@ struct PlParams {
   unsigned b_tap_stride;                // elements
   int k_chunk;                          // wgrad: pixels of the reduction per grid.z slice (multiple of 32)
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
+  int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
+                                        // 2 = epilogue without global loads / stores
   IgemmGeom g;
 };
 
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       const int m = m0 + wm * TM * 32 + tm * 32 + row;
       const float4 v0 = stcat_ld4(&ew[row * LDE + ecol]), v1 = stcat_ld4(&ew[row * LDE + ecol + 4]);
       float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (m < p.M) {
+      if (m < p.M && !((p.debug & 2) && x[0] != 12345.f)) {
         STCAT_UNROLL
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
         if (p.Rh) {
@@ -279,11 +284,21 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
-        if (p.Yh) {
+        if (p.Mi) {
+          const unsigned bits = p.Mi[((long)m * p.ldc + n) >> 3];
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] = ((bits >> e) & 1u) ? x[e] * ms[e] : 0.f;
+        } else if (p.Yh) {
           float yy[8];
           stcat_join8(p.Yh + (long)m * p.ldc + n, p.Yl + (long)m * p.ldc + n, yy);
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = yy[e] > 0.f ? x[e] * ms[e] : 0.f;
+        }
+        if (p.Mo) {
+          unsigned bits = 0u;
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) bits |= (x[e] > 0.f ? 1u : 0u) << e;
+          p.Mo[((long)m * p.ldc + n) >> 3] = (unsigned char)bits;
         }
         if (p.Ch) {
           bf16x8 h8, l8;
@@ -464,7 +479,7 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       STCAT_UNROLL
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        atomicAdd(&p.Wf[(long)m * p.ldc + n], acc[tm][tn][r]);
+        if (!((p.debug & 1) && acc[tm][tn][r] != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], acc[tm][tn][r]);
       }
     }
   }

@@ -306,16 +306,19 @@ int pl_prepare(K kernel, int lds_bytes) {
     STCAT_LAUNCH((KERNEL<BM_, BN_, WM_, WN_>), GRID, dim3(512), lds_, st, p);                          \
   }
 
+int g_pl_debug = 0;   // stcat_debug_pl_flags (timing experiments)
 int g_pl_force = -1;  // stcat_debug_force_pl_tile: index into the tile table below, -1 = heuristic
 struct PlTile { int bm, bn; float eff; };
 // relative cost per MAC of each tile shape (bigger wave tiles amortise fragment reads and DMA issue better)
-const PlTile kPlTiles[5] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f}};
+// (224 x 256: 7 x 32 rows, 8 waves side by side — 50176 = 224 * 224 rows of layer3 fill 224 of 256 CUs in ONE round)
+const PlTile kPlTiles[6] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f},
+                            {224, 256, 1.04f}};
 
 int pick_pl_tile(int M, int N) {
   if (g_pl_force >= 0 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
   int best = -1;
   float best_cost = 0.f;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 6; ++i) {
     const PlTile& tl = kPlTiles[i];
     if (N % tl.bn != 0) continue;
     const long tiles = (long)cdiv(M, tl.bm) * (N / tl.bn);
@@ -326,7 +329,9 @@ int pick_pl_tile(int M, int N) {
   return best;
 }
 
-int launch_pl_fwd(const PlParams& p, hipStream_t st) {
+int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
+  PlParams p = p_;
+  p.debug = g_pl_debug;
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
@@ -339,6 +344,7 @@ int launch_pl_fwd(const PlParams& p, hipStream_t st) {
     case 1: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 128, 4, 2, grid) break;
     case 2: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 128, 256, 2, 4, grid) break;
     case 3: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 128, 128, 2, 4, grid) break;
+    case 5: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 224, 256, 1, 8, grid) break;
     default: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 64, 8, 1, grid) break;
   }
   return launch_status();
@@ -357,7 +363,7 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   int chunk = cdiv(red, nsplit);
   chunk = ((chunk + 31) / 32) * 32;
   nsplit = cdiv(red, chunk);
-  p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk;
+  p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk; p.debug = g_pl_debug;
   const dim3 grid(tiles, 1, nsplit);
   if (BM == 256 && BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 256, 2, 4, grid)
   else if (BM == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 128, 4, 2, grid)
@@ -801,21 +807,27 @@ int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out,
 
 // ---- plane-format backbone (mma mode 4): every tensor is a pair of bf16 planes (hi, lo) ------------------------
 int stcat_debug_force_pl_tile(int index) {
-  if (index < -1 || index > 4) return fail("debug_force_pl_tile: index must be -1 .. 4");
+  if (index < -1 || index > 5) return fail("debug_force_pl_tile: index must be -1 .. 5");
   g_pl_force = index;
   return 0;
 }
 
+int stcat_debug_pl_flags(int flags) {
+  g_pl_debug = flags;
+  return 0;
+}
+
 int stcat_pl_conv_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* scale,
-                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf, int n, int H,
-                      int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, void* stream) {
+                      const float* bias, const void* rh, const void* rl, void* yh, void* yl, float* yf,
+                      unsigned char* ymask, int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                      int relu, void* stream) {
   if (Cin % 32 != 0 || Cout % 64 != 0) return fail("pl_conv_fwd: need Cin %% 32 == 0 and Cout %% 64 == 0 (%d, %d)", Cin, Cout);
   if (!aligned16(xh) || !aligned16(xl) || !aligned16(wh) || !aligned16(wl)) return fail("pl_conv_fwd: planes must be 16-byte aligned");
   if (!yh && !yf) return fail("pl_conv_fwd: no output");
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   PlParams p = {};
   p.Ah = (const __bf16*)xh; p.Al = (const __bf16*)xl; p.Bh = (const __bf16*)wh; p.Bl = (const __bf16*)wl;
-  p.Ch = (__bf16*)yh; p.Cl = (__bf16*)yl; p.Cf = yf; p.scale = scale; p.bias = bias;
+  p.Ch = (__bf16*)yh; p.Cl = (__bf16*)yl; p.Cf = yf; p.Mo = ymask; p.scale = scale; p.bias = bias;
   p.Rh = (const __bf16*)rh; p.Rl = (const __bf16*)rl;
   p.a_bytes = plane_bytes((long)n * H * W * Cin); p.b_bytes = plane_bytes((long)Cout * KH * KW * Cin);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_fwd: a plane exceeds 2 GB");
@@ -826,7 +838,8 @@ int stcat_pl_conv_fwd(const void* xh, const void* xl, const void* wh, const void
 }
 
 int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const void* tl, const void* addh,
-                        const void* addl, const void* yh, const void* yl, const float* mask_scale, void* dxh, void* dxl,
+                        const void* addl, const void* yh, const void* yl, const unsigned char* ybits,
+                        const float* mask_scale, void* dxh, void* dxl,
                         void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, void* stream) {
   if ((dx2h != nullptr) != (dx2_scale != nullptr)) return fail("pl_conv_dgrad: dx2 and dx2_scale go together");
@@ -835,7 +848,7 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
   PlParams p = {};
   p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)th; p.Bl = (const __bf16*)tl;
   p.Ch = (__bf16*)dxh; p.Cl = (__bf16*)dxl; p.Rh = (const __bf16*)addh; p.Rl = (const __bf16*)addl;
-  p.Yh = (const __bf16*)yh; p.Yl = (const __bf16*)yl; p.mscale = mask_scale;
+  p.Yh = (const __bf16*)yh; p.Yl = (const __bf16*)yl; p.Mi = ybits; p.mscale = mask_scale;
   p.C2h = (__bf16*)dx2h; p.C2l = (__bf16*)dx2l; p.c2scale = dx2_scale;
   p.a_bytes = plane_bytes((long)n * OH * OW * Cout); p.b_bytes = plane_bytes((long)Cout * KH * KW * Cin);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_dgrad: a plane exceeds 2 GB");

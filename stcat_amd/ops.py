@@ -919,11 +919,12 @@ WEIGHT_EPOCH = 0  # bumped by the fused optimizer (it updates parameters through
 
 class Planes:
     """A tensor held as two bf16 planes (hi = bf16(x), lo = bf16(x - hi)) in ONE allocation [2, *shape]."""
-    __slots__ = ("t",)
+    __slots__ = ("t", "mask")
 
-    def __init__(self, t: torch.Tensor):
+    def __init__(self, t: torch.Tensor, mask: Optional[torch.Tensor] = None):
         assert t.dtype == _bf16 and t.shape[0] == 2 and t.is_contiguous()
         self.t = t
+        self.mask = mask  # optional bit mask (x > 0), uint8 [rows, C / 8], written by the producing conv epilogue
 
     @staticmethod
     def empty(like: torch.Tensor, *shape) -> "Planes":
@@ -976,15 +977,19 @@ def pl_maxpool_raw(x: torch.Tensor) -> Planes:
 
 
 def pl_conv_fwd_raw(x: Planes, w: Planes, scale, bias, res: Optional[Planes], stride, pad, relu, planes_out=True,
-                    f32_out=False):
-    """w: planes of the OHWI weight [Cout,KH,KW,Cin].  Returns (y planes | None, y fp32 | None)."""
+                    f32_out=False, want_mask=False):
+    """w: planes of the OHWI weight [Cout,KH,KW,Cin].  Returns (y planes | None, y fp32 | None); with want_mask the
+    planes carry the bit mask (y > 0) for the backward pass."""
     n, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
     yp = Planes.empty(x.t, n, OH, OW, Cout) if planes_out else None
     yf = torch.empty(n, OH, OW, Cout, device=x.device, dtype=_f32) if f32_out else None
+    if want_mask and yp is not None:
+        yp.mask = torch.empty(n * OH * OW, Cout // 8, device=x.device, dtype=torch.uint8)
     L.call("stcat_pl_conv_fwd", x.h, x.l, w.h, w.l, L._ptr(scale), L._ptr(bias), *_pl(res), *_pl(yp), L._ptr(yf),
-           n, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), L.stream_of(x.t))
+           L._ptr(yp.mask if yp is not None else None), n, H, W, Cin, Cout, KH, KW, stride, pad, int(relu),
+           L.stream_of(x.t))
     return yp, yf
 
 
@@ -995,7 +1000,9 @@ def pl_conv_dgrad_raw(g: Planes, wt: Planes, in_shape, k, stride, pad, add: Opti
     Cout = g.shape[-1]
     dx = Planes.empty(g.t, n, H, W, Cin) if out is None else out
     dx2 = Planes.empty(g.t, n, H, W, Cin) if scale2 is not None else None
-    L.call("stcat_pl_conv_dgrad", g.h, g.l, wt.h, wt.l, *_pl(add), *_pl(mask_y), L._ptr(mask_scale), dx.h, dx.l,
+    bits = mask_y.mask if mask_y is not None else None
+    L.call("stcat_pl_conv_dgrad", g.h, g.l, wt.h, wt.l, *_pl(add), *(_pl(mask_y) if bits is None else (None, None)),
+           L._ptr(bits), L._ptr(mask_scale), dx.h, dx.l,
            *_pl(dx2), L._ptr(scale2), n, H, W, Cin, Cout, k, k, stride, pad, L.stream_of(g.t))
     return dx if scale2 is None else (dx, dx2)
 
@@ -1071,3 +1078,49 @@ class WeightPlanes:
             L.call("stcat_weight_planes_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
             self.state = state
         return self.fwd, self.tr
+
+
+_WGRAD_STREAMS = {}
+WGRAD_STREAM_ENABLED = not os.environ.get("STCAT_NO_WGRAD_STREAM")
+
+
+class WgradStream:
+    """`with WgradStream(x): <launch>` puts a weight-gradient launch on a second HIP stream, ordered after everything
+    queued so far on the current stream; `keep(...)` tells the caching allocator which tensors that launch reads;
+    `join(*outputs)` makes the current stream wait for all of them.  A no-op on the emulator / when disabled."""
+
+    def __init__(self, like: torch.Tensor):
+        self.active = WGRAD_STREAM_ENABLED and L._backend == "hip" and like.is_cuda
+        if self.active:
+            dev = like.device
+            self.main = torch.cuda.current_stream(dev)
+            self.side = _WGRAD_STREAMS.get(dev)
+            if self.side is None:
+                self.side = _WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            self.ctx = None
+
+    def __enter__(self):
+        if self.active:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def keep(self, *tensors):
+        if self.active:
+            for t in tensors:
+                t = t.t if isinstance(t, Planes) else t
+                if torch.is_tensor(t):
+                    t.record_stream(self.side)
+
+    def join(self, *outputs):
+        if self.active:
+            self.main.wait_stream(self.side)
+            for t in outputs:
+                if torch.is_tensor(t):
+                    t.record_stream(self.main)

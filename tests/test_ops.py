@@ -181,14 +181,20 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
     close(ops.pl_join(wt), wd.view(Cout, k * k, Cin).permute(1, 2, 0), 2e-5, "transposed weight planes")
     L.call("stcat_debug_force_pl_tile", tile)
     try:
-        yp, yf = ops.pl_conv_fwd_raw(xp, wp, sd, bd, rp, stride, pad, relu, planes_out=True, f32_out=True)
+        yp, yf = ops.pl_conv_fwd_raw(xp, wp, sd, bd, rp, stride, pad, relu, planes_out=True, f32_out=True, want_mask=True)
+        # the bit mask written by the epilogue == (y > 0), 8 columns per byte
+        bits = ((yf.reshape(-1, Cout // 8, 8) > 0).to(torch.int32) << torch.arange(8, device=yf.device).to(torch.int32)).sum(-1)
+        assert torch.equal(yp.mask.to(torch.int32), bits), "ReLU bit mask"
         gyd = gy.permute(0, 2, 3, 1).contiguous().to(dev)
         G, dres = ops.pl_act_bwd_raw(gyd, yf, sd, want_g=True, want_res=True, relu=relu)
         dx = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad)
         ymask = torch.randn_like(xd)
         msc = torch.rand(xd.shape[-1], device=dev) + 0.5
         dx3 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, mask_y=ops.pl_split(ymask), mask_scale=msc)
-        dx4, dx5 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, add=dx, mask_y=ops.pl_split(ymask), scale2=msc)
+        ymp = ops.pl_split(ymask)
+        ymp.mask = ((ymask.reshape(-1, Cin // 8, 8) > 0).to(torch.int32)
+                    << torch.arange(8, device=ymask.device).to(torch.int32)).sum(-1).to(torch.uint8)
+        dx4, dx5 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, add=dx, mask_y=ymp, scale2=msc)  # bit-mask form
         dw = ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad) if wgrad else None
         gs = ops.pl_scale_raw(G, msc[:1].expand(Cout).contiguous())
     finally:

@@ -52,14 +52,16 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--only", default="")
     ap.add_argument("--pl-tile", type=int, default=-1, help="force the plane-GEMM tile index (bf16x3p)")
+    ap.add_argument("--pl-flags", type=int, default=0, help="stcat_debug_pl_flags (timing experiments)")
     args = ap.parse_args()
     L.load(os.environ.get("STCAT_LIB_OVERRIDE", L.LIB_PATH))  # experiment builds only
     L.set_mma_mode(args.mma)
     if args.tile:
         bm, bn = [int(v) for v in args.tile.split("x")]
         L.call("stcat_debug_force_tile", bm, bn)
+    L.call("stcat_debug_pl_flags", args.pl_flags)
     dev = torch.device("cuda:0")
-    print(f"# mma={args.mma} tile={args.tile or 'auto'} variant={args.variant}")
+    print(f"# mma={args.mma} pl_tile={args.pl_tile} pl_flags={args.pl_flags} tile={args.tile or 'auto'} variant={args.variant}")
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     for name, n, H, W, Cin, Cout, k, stride, pad in SHAPES:
         if args.only and args.only not in name:
