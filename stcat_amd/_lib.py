@@ -141,9 +141,11 @@ def _ptr(t):
 
 
 def stream_of(t: torch.Tensor):
+    """raw hipStream_t of torch's CURRENT stream on t's device (honours torch.cuda.stream(...) contexts)"""
     if _backend == "emu":
         return None
-    return torch.cuda.current_stream(t.device).cuda_stream
+    # torch.cuda.current_stream() builds a Stream object (~5 us, ~1750 launches per step); the raw getter is ~0.3 us
+    return torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None else torch.cuda.current_device())
 
 
 def check_tensor(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:

@@ -130,6 +130,7 @@ class _BackboneFn(Function):
             x = y
         ctx.tape = tape
         ctx.body = body
+        ctx.plist = weights
         return x
 
     @staticmethod
@@ -168,7 +169,7 @@ class _BackboneFn(Function):
             else:
                 dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dz, mask_y=x, scale2=s3_below, wt=_wt(w1))
         out = []
-        for w in ctx.body.parameters():  # same order as the *weights passed to forward
+        for w in ctx.plist:  # same order as the *weights passed to forward
             g = grads.get(id(w))
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)  # OHWI buffer seen as [O,I,KH,KW]
         ctx.tape = None
@@ -222,6 +223,7 @@ class _BackboneFnPl(Function):
         ctx.tape = tape
         ctx.wt = wt
         ctx.body = body
+        ctx.plist = weights
         return yf
 
     @staticmethod
@@ -266,7 +268,7 @@ class _BackboneFnPl(Function):
                 dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=dz, mask_y=x, scale2=s3_below)
         wg.join(*grads.values())
         out = []
-        for w in ctx.body.parameters():
+        for w in ctx.plist:
             g = grads.get(id(w))
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)
         ctx.tape = None
@@ -288,13 +290,16 @@ class Backbone(nn.Module):
             if not train_backbone or ("layer2" not in n_ and "layer3" not in n_ and "layer4" not in n_):
                 p.requires_grad_(False)
         self.num_channels = 2048
+        self._plist = None  # cached list(body.parameters()) (walking the module tree costs ~1 ms per step)
 
     def features_nhwc(self, frames: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
             # first module of the hot path to run in a step: open the step's dropout counter range (drop-in mode has
             # no other place to do it — the reference's train loop is unmodified)
             ops.dropout_auto_begin_step(frames.device)
-        weights = [p for p in self.body.parameters()]
+        weights = self._plist  # same order as body.parameters(): the backward returns one gradient per entry
+        if weights is None or len(weights) == 0:
+            weights = self._plist = [p for p in self.body.parameters()]
         if ops.L.get_mma_mode() == "bf16x3p":
             return _BackboneFnPl.apply(frames, self.body, *weights)
         return _BackboneFn.apply(frames, self.body, *weights)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""MFMA utilisation per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES pass.
+
+MfmaUtil (rocprofv3's own derived metric, counters.txt) = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) x
+SIMD_NUM): matrix-pipe busy cycles over all SIMD-cycles of the dispatch.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles
+(= 32 x N for v_mfma_f32_32x32x16_bf16, MI355X_MICROARCH.md); SIMD_NUM = 256 CUs x 4.  Per launch, averaged."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+SIMDS = 256 * 4
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:70]
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k].add(r.get("Dispatch_Id", "0"))
+out = {}
+for k, v in agg.items():
+    if not any(s in k for s in ("igemm", "mha_self", "attn_q1")):
+        continue
+    n = max(len(launches[k]), 1)
+    busy, act = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), v.get("GRBM_GUI_ACTIVE", 0.0)
+    if act <= 0:
+        continue
+    out[k] = {"launches": n, "mfma_util_pct": round(100.0 * busy / (act * SIMDS), 2),
+              "mfma_busy_cycles_per_launch": round(busy / n), "gpu_active_cycles_per_launch": round(act / n)}
+print(json.dumps({"note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), rocprofv3 --pmc, own pass",
+                  "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"]))}))
