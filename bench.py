@@ -424,6 +424,29 @@ def main():
                     "note": "10 fp32 accesses per parameter (g twice); HBM-bound; ms = device time (HIP events)"}
         del opt, ema
 
+    # Evaluation path (engine/evaluate.py:97-119): two forward passes on the even / odd frames, device-side T x T map
+    # argmax, span union, linear_interp of skipped frames — videos/s of test_net.py's inner loop on the same clip.
+    eval_path = None
+    if world == 1 and not args.no_exact:
+        from stcat_amd.pipeline import build_postprocessors, evaluate_video
+        post = build_postprocessors()
+        was_training = model.training
+        model.eval()
+        sizes = torch.tensor([[float(res), float(res)]], device=dev).repeat(T, 1)
+        ids = [list(range(0, 2 * T, 2))]  # every second frame of the source video: the rest are interpolated
+        with torch.no_grad():
+            evaluate_video(model, post, videos, ["synthetic"], sizes, ids, interpolate=True)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                boxes_e, span_e = evaluate_video(model, post, videos, ["synthetic"], sizes, ids, interpolate=True)
+            fence()
+        dt_e = (time.perf_counter() - t1) / 5
+        eval_path = {"value": round(1.0 / dt_e, 3), "unit": "videos/sec", "ms_per_video": round(1e3 * dt_e, 2),
+                     "what": f"2-pass eval (2 x {T // 2} frames) + PostProcess + span union + linear_interp "
+                             f"({len(boxes_e)} boxes out), no_grad, eval mode"}
+        model.train(was_training)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N=1 only: other ranks would idle at the barrier
         cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, min(os.cpu_count() or 1, args.cpu_threads))
@@ -445,7 +468,7 @@ def main():
                        "launch": "one hipGraph per step" if args.graph else "eager (launch by launch)",
                        "allreduce_bytes": reducer.message_bytes},
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "other_modes": other_modes,
-            "optimizer_tail": opt_tail,
+            "optimizer_tail": opt_tail, "eval_path": eval_path,
             "timed_region": "forward + VideoSTGLoss + backward (+ gradient exchange at N > 1); the target-only index "
                             "tensors of the loss (LossPlan) and its 1-element box-count all-reduce "
                             "(criterion.py:175-178) are built once per batch OUTSIDE the timed step (they depend on "

@@ -475,3 +475,20 @@ def post_process(pred_sted, pred_boxes, sizes, frame_ids: Sequence[int], duratio
     flat = int(m.flatten().max(dim=0)[1])
     s, e = flat // t, flat % t
     return boxes, [frame_ids[s], frame_ids[e] + 1], flat
+
+
+def linear_interp(bbox_dict):
+    """engine/evaluate.py:11-35 restated (plain Python on lists, as the reference): {frame_id: [[x1,y1,x2,y2]]} ->
+    the same dict with every missing frame between neighbours filled by linear interpolation."""
+    fids = sorted(bbox_dict)
+    if len(fids) < 2:
+        return bbox_dict
+    for lf, rf in zip(fids[:-1], fids[1:]):
+        gap = rf - lf
+        if gap > 1:
+            d = [(bbox_dict[rf][0][c] - bbox_dict[lf][0][c]) / gap for c in range(4)]
+            for step in range(1, gap):
+                bbox_dict[lf + step] = [[bbox_dict[lf][0][c] + step * d[c] for c in range(4)]]
+    fids = sorted(bbox_dict)
+    assert max(fids) - min(fids) + 1 == len(fids)
+    return {f: bbox_dict[f] for f in fids}

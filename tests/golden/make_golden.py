@@ -393,8 +393,31 @@ def op_level_vectors():
     return g
 
 
+def eval_vectors():
+    """Known answers of the evaluation tail (engine/evaluate.py:11-35 linear_interp, :111-119 span union)."""
+    install_stubs()
+    sys.path.insert(0, REF)
+    from engine.evaluate import linear_interp
+    g = {}
+    # merged even/odd passes of a clip whose frame ids have gaps (sampled frames): ids and xyxy boxes
+    ids = np.array([100, 101, 103, 104, 108, 109, 115], dtype=np.int64)
+    boxes = (synth.hash_uniform("op/interp/boxes", len(ids) * 4).reshape(len(ids), 4) * 100 + 200).astype(np.float32)
+    d = {int(f): [[float(v) for v in b]] for f, b in zip(ids, boxes)}
+    out = linear_interp(dict(d))
+    g["interp/ids"], g["interp/boxes"] = ids, boxes
+    g["interp/out_ids"] = np.array(sorted(out), dtype=np.int64)
+    g["interp/out_boxes"] = np.array([out[f][0] for f in sorted(out)], dtype=np.float64)
+    one = linear_interp({7: [[1.0, 2.0, 3.0, 4.0]]})            # fewer than two frames: returned unchanged
+    g["interp/single_ids"] = np.array(sorted(one), dtype=np.int64)
+    return g
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    if sys.argv[1:] == ["eval"]:
+        np.savez_compressed(os.path.join(out_dir, "eval.npz"), **eval_vectors())
+        print("eval.npz written")
+        return
     torch.set_num_threads(8)
     np.savez_compressed(os.path.join(out_dir, "ops.npz"), **op_level_vectors())
     print("ops.npz written")

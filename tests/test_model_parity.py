@@ -400,6 +400,10 @@ def test_gpu_two_pass_eval_path():
         sizes = torch.tensor([[float(res), float(res)]], device=dev).repeat(T, 1)
         ids = [list(range(100, 100 + T))]
         boxes, union = evaluate_video(model, build_postprocessors(), NestedTensor(frames, mask, [T]), ["q"], sizes, ids)
+        # the same with gaps in the frame ids: engine/evaluate.py:114 interpolates the frames the sampler skipped
+        gap_ids = [[100, 101, 103, 104, 108, 109, 110, 115]]
+        dense, _ = evaluate_video(model, build_postprocessors(), NestedTensor(frames, mask, [T]), ["q"], sizes, gap_ids,
+                                  interpolate=True)
     finally:
         _lib.set_mma_mode("f32")
     assert sorted(f for _, f in boxes) == ids[0] and all(b.shape == (4,) for b in boxes.values())
@@ -414,3 +418,9 @@ def test_gpu_two_pass_eval_path():
         for k, f in enumerate(ids[0][start::2]):
             close(boxes[(0, f)], b[k], OUT_TOL * res, f"eval box frame {f}")
     assert union == [[min(spans[0][0], spans[1][0]), max(spans[0][1], spans[1][1])]]
+    # interpolated boxes == the oracle's linear_interp of the merged per-frame boxes
+    assert sorted(f for _, f in dense) == list(range(100, 116))
+    merged = {f: [[float(v) for v in boxes[(0, ids[0][k])].double().cpu()]] for k, f in enumerate(gap_ids[0])}
+    want = O.linear_interp(merged)
+    for f in range(100, 116):
+        close(dense[(0, f)], torch.tensor(want[f][0], dtype=torch.float64), 1e-9, f"interpolated box {f}")

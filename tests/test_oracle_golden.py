@@ -121,3 +121,23 @@ def test_op_vectors(golden_dir):
         pb, st, _ = O.post_process(sted, boxes, sizes, list(range(50, 50 + T)), dur)
         assert st == [int(v) for v in g[f"post/dur{dur}/sted"][0]], dur
     _close(pb.numpy(), g["post/boxes"], 1e-6, "post boxes")
+
+
+def test_linear_interp_against_reference_golden(golden_dir):
+    """engine/evaluate.py:11-35: the oracle restatement AND the product's tensor form against the reference's output"""
+    import numpy as np
+    import torch
+    from oracle import stcat_oracle as O
+    from stcat_amd.pipeline import linear_interp
+    g = np.load(os.path.join(golden_dir, "eval.npz"))
+    ids, boxes = g["interp/ids"], g["interp/boxes"]
+    d = {int(f): [[float(v) for v in b]] for f, b in zip(ids, boxes)}
+    out = O.linear_interp(dict(d))
+    assert sorted(out) == g["interp/out_ids"].tolist()
+    assert np.array_equal(np.array([out[f][0] for f in sorted(out)]), g["interp/out_boxes"])      # bit-exact (fp64)
+    perm = torch.randperm(len(ids), generator=torch.Generator().manual_seed(0))                  # any input order
+    full, bx = linear_interp(ids[perm.numpy()].tolist(), torch.from_numpy(boxes)[perm])
+    assert full == g["interp/out_ids"].tolist()
+    assert np.array_equal(bx.numpy(), g["interp/out_boxes"])
+    full1, bx1 = linear_interp([7], torch.tensor([[1.0, 2.0, 3.0, 4.0]]))
+    assert full1 == g["interp/single_ids"].tolist() and bx1.shape == (1, 4)
