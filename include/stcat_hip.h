@@ -203,6 +203,17 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
                        const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
                        int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
                        float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
+/* The same core on the bf16 matrix pipe (split-bf16 x3 products, fp32 accumulate) with an online softmax: any S,
+ * nothing but the row log-sum-exp lse[B,H,S] kept for backward (no probability stash); no head-mean weights.
+ * stcat_mha_bs_bwd recomputes the probabilities from q, k and lse and produces dq, dk, dv in ONE launch (S <= 256).
+ * Replaces nn.MultiheadAttention's core in modal_encoder.py:161-168, 180-185, 228-242 and query_decoder.py:341. */
+int stcat_mha_bs_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
+                     int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p, long drop_seed,
+                     long drop_offset, const long* drop_base, void* stream);
+int stcat_mha_bs_bwd(const float* q, const float* k, const float* v, const unsigned char* kpm, const float* out,
+                     const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int H, int S, int ldq,
+                     int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, float drop_p, long drop_seed,
+                     long drop_offset, const long* drop_base, void* stream);
 /* head-averaged weights [B,S,S] (need_weights=True; consumed at pipeline.py:84-85); in train mode these are
  * the DROPPED probabilities, as torch returns them */
 int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, float drop_p, long drop_seed,

@@ -6,6 +6,7 @@
 
 #include "../../include/stcat_hip.h"
 #include "attention.h"
+#include "attention_bs.h"
 #include "optim.h"
 #include "igemm.h"
 #include "igemm_bs.h"
@@ -927,6 +928,60 @@ int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks
   if (n_entries <= 0 || total_blocks <= 0) return fail("weight_planes_multi: empty table");
   STCAT_LAUNCH(weight_planes_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WplEntry*)table,
                n_entries);
+  return launch_status();
+}
+
+// ---- self-attention on the bf16 pipe (attention_bs.h) ---------------------------------------------------------
+#define STCAT_NW_SWITCH(NW_, CALL)                                   \
+  switch (NW_) {                                                     \
+    case 1: { constexpr int NW = 1; CALL; } break;                   \
+    case 2: { constexpr int NW = 2; CALL; } break;                   \
+    case 3: { constexpr int NW = 3; CALL; } break;                   \
+    case 4: { constexpr int NW = 4; CALL; } break;                   \
+    case 5: { constexpr int NW = 5; CALL; } break;                   \
+    case 6: { constexpr int NW = 6; CALL; } break;                   \
+    case 7: { constexpr int NW = 7; CALL; } break;                   \
+    default: { constexpr int NW = 8; CALL; } break;                  \
+  }
+
+int stcat_mha_bs_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
+                     int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p, long drop_seed,
+                     long drop_offset, const long* drop_base, void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0) return fail("mha_bs_fwd: bad shape");
+  if ((ldq | ldk | ldv | ldo) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o))
+    return fail("mha_bs_fwd: q/k/v/o must be 16-byte aligned with ld %% 4 == 0");
+  AttnBsParams p = {};
+  p.Q = q; p.K = k; p.V = v; p.O = o; p.lse = lse; p.kpm = kpm; p.B = B; p.H = H; p.S = S;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
+  const int nq = cdiv(S, 32), nw = nq < 8 ? nq : 8;
+  const int lds = 4 * 256 * 64 + 256 * 4;
+  hipStream_t st = (hipStream_t)stream;
+  STCAT_NW_SWITCH(nw, {
+    if (int rc = pl_prepare(mha_bs_fwd_kernel<NW>, lds)) return rc;
+    STCAT_LAUNCH((mha_bs_fwd_kernel<NW>), dim3(B * H, cdiv(nq, nw)), dim3(64 * NW), lds, st, p);
+  })
+  return launch_status();
+}
+
+int stcat_mha_bs_bwd(const float* q, const float* k, const float* v, const unsigned char* kpm, const float* out,
+                     const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int H, int S, int ldq,
+                     int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, float drop_p, long drop_seed,
+                     long drop_offset, const long* drop_base, void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0) return fail("mha_bs_bwd: bad shape");
+  if (S > 256) return fail("mha_bs_bwd: S=%d exceeds 256 tokens (training on longer token rows is not built yet)", S);
+  if ((ldq | ldk | ldv | ldo | ldg | ldgv) % 4 != 0) return fail("mha_bs_bwd: ld %% 4 != 0");
+  AttnBsParams p = {};
+  p.Q = q; p.K = k; p.V = v; p.lse = const_cast<float*>(lse); p.kpm = kpm; p.dO = dout; p.dQ = dq; p.dK = dk; p.dV = dv;
+  p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldg = ldg; p.ldgv = ldgv; p.scale = scale;
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
+  const int nw = cdiv(S, 32);
+  const int lds = 8 * nw * 32 * 64 + 3 * nw * 32 * 4;
+  hipStream_t st = (hipStream_t)stream;
+  STCAT_NW_SWITCH(nw, {
+    if (int rc = pl_prepare(mha_bs_bwd_kernel<NW>, lds)) return rc;
+    STCAT_LAUNCH((mha_bs_bwd_kernel<NW>), dim3(B * H), dim3(64 * NW), lds, st, p, out);
+  })
   return launch_status();
 }
 

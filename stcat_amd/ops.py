@@ -627,6 +627,26 @@ class MhaSelfFn(Function):
             kp = _c(kpm.to(torch.uint8))
         SP = ((S + 31) // 32) * 32
         o = _empty(v, B, S, D)
+        ctx.scale = scale
+        ctx.packed_qk = packed_qk
+        ctx.need_weights = need_weights
+        # bf16-pipe kernels (csrc/attention_bs.h): online softmax, any S, only the row log-sum-exp is kept for backward.
+        # The fp32-MFMA kernels remain for the exact-fp32 mode and for the one caller that consumes the head-mean
+        # weights (the time decoder's self-attention, T queries).
+        ctx.bs = (not need_weights) and L.get_mma_mode() != "f32"
+        if ctx.bs:
+            keep = any(ctx.needs_input_grad[:3])
+            lse = _empty(v, B, H, S) if keep else None
+            drop = (0.0, 0, 0, None)
+            if drop_p > 0.0:
+                drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP, v.device)
+            L.call("stcat_mha_bs_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), L._ptr(lse),
+                   B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, *drop, L.stream_of(v))
+            ctx.drop = drop
+            if keep:
+                ctx.save_for_backward(q, k, v, o, lse, kp)
+            ctx.mark_non_differentiable()
+            return o, None
         # probabilities are kept only when somebody will read them: backward, or the head-mean weights
         keep = need_weights or any(ctx.needs_input_grad[:3])
         pt = _empty(v, B, H, SP, SP) if keep else None
@@ -642,9 +662,6 @@ class MhaSelfFn(Function):
         ctx.drop = drop
         if keep:
             ctx.save_for_backward(q, k, v, o, pt)
-        ctx.scale = scale
-        ctx.packed_qk = packed_qk
-        ctx.need_weights = need_weights
         if need_weights:
             return o, wts
         ctx.mark_non_differentiable()
@@ -652,6 +669,25 @@ class MhaSelfFn(Function):
 
     @staticmethod
     def backward(ctx, do, dwts):
+        if ctx.bs:
+            q, k, v, o, lse, kp = ctx.saved_tensors
+            B, S, D = v.shape
+            H = D // 32
+            do = _c(do)
+            if ctx.packed_qk:
+                dqk = _empty(v, B, S, 2 * D)
+                dq, dk, ldg_qk = dqk[:, :, :D], dqk[:, :, D:], 2 * D
+            else:
+                dq = _empty(v, B, S, D)
+                dk = _empty(v, B, S, D)
+                ldg_qk = D
+            dv = _empty(v, B, S, D)
+            L.call("stcat_mha_bs_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), do.data_ptr(),
+                   lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, _ld3(q), _ld3(k), _ld3(v), D,
+                   ldg_qk, D, ctx.scale, *ctx.drop, L.stream_of(v))
+            if ctx.packed_qk:
+                return dqk, None, dv, None, None, None, None, None
+            return dq, dk, dv, None, None, None, None, None
         q, k, v, o, pt = ctx.saved_tensors
         B, S, D = v.shape
         H = D // 32

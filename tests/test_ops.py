@@ -495,6 +495,40 @@ def _mha_dropout_case(dev, B, S, H, need_w, pdrop=0.25):
     close(vd.grad, vr.grad, TOL, tag + " dv")
 
 
+@both
+def _mha_bs(dev, big):
+    """bf16-pipe self-attention (csrc/attention_bs.h): online softmax, log-sum-exp stash, recompute backward."""
+    L.set_mma_mode("bf16x3")
+    try:
+        _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)       # two key tiles, ragged
+        _mha_case(dev, 1, 65, 1, need_w=False, packed=False, masked=True)      # temporal-layer shape (T + 1)
+        _mha_case(dev, 1, 150, 2, need_w=False, packed=True, masked=True)      # two 128-key chunks: online rescale
+        _mha_dropout_case(dev, 2, 37, 2, need_w=False)
+        # the rescale branch forced: one late key dominates every row (its chunk raises the running max by ~40)
+        B, S, H, D = 1, 140, 1, 32
+        qk, v = rnd(B, S, 2 * D, seed=11), rnd(B, S, D, seed=12)
+        qk[0, :, :D] = qk[0, :, :D].abs() + 0.5
+        qk[0, 135, D:] = 8.0
+        o_ref, _ = _mha_ref(qk[..., :D], qk[..., D:], v, None, 32 ** -0.5, H)
+        with torch.no_grad():
+            o, _ = ops.mha_self_packed(qk.to(dev), v.to(dev), None, 32 ** -0.5)
+        close(o, o_ref, TOL, "online-softmax rescale (late dominant key)")
+        # more than 256 tokens per row (a 405 x 720 clip: 13 x 23 + 10 + 1 = 310): forward through key super-chunks
+        B, S, H = 1, 310, 2
+        qk, v = rnd(B, S, 2 * H * 32, seed=21), rnd(B, S, H * 32, seed=22)
+        kpm = torch.zeros(B, S, dtype=torch.bool)
+        kpm[0, 300:] = True
+        o_ref, _ = _mha_ref(qk[..., :H * 32], qk[..., H * 32:], v, kpm, 32 ** -0.5, H)
+        with torch.no_grad():
+            o, _ = ops.mha_self_packed(qk.to(dev), v.to(dev), kpm.to(dev), 32 ** -0.5)
+        close(o, o_ref, TOL, "S = 310 forward")
+        if big:
+            _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)  # the C3 spatial layer
+            _mha_dropout_case(dev, 4, 207, 8, need_w=False, pdrop=0.1)
+    finally:
+        L.set_mma_mode("f32")
+
+
 def _q1_dropout_case(dev, B, S, H, pdrop=0.25):
     D = H * 32
     q1, k1, v = rnd(B, D, seed=1), rnd(B, S, D, seed=3), rnd(B, S, D, seed=5)

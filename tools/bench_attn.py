@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stcat_amd import _lib as L, ops
 L.load()
+L.set_mma_mode(os.environ.get("MMA", "bf16x3"))   # bf16x3: bf16-pipe kernels (attention_bs.h); f32: fp32-MFMA kernels
 dev = torch.device("cuda:0")
 B, H, S = (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 8, (int(sys.argv[1]) if len(sys.argv) > 1 else 207)
 D = H * 32

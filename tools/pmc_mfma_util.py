@@ -13,15 +13,21 @@ import sys
 SIMDS = 256 * 4
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(set)
+per_dispatch = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0][:70]
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            per_dispatch[(k, r.get("Dispatch_Id", "0"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
             launches[k].add(r.get("Dispatch_Id", "0"))
+# one CSV row per counter instance (SE / XCD): SQ counters add up over instances, GRBM_GUI_ACTIVE is the wall clock of
+# the dispatch on every instance -> max (rocprofv3's own MfmaUtil expression: reduce(sum) / reduce(max))
+for (k, _), cs in per_dispatch.items():
+    for name, vals in cs.items():
+        agg[k][name] += max(vals) if name.startswith("GRBM") else sum(vals)
 out = {}
 for k, v in agg.items():
-    if not any(s in k for s in ("igemm", "mha_self", "attn_q1")):
+    if not any(s in k for s in ("igemm", "mha_", "attn_q1")):
         continue
     n = max(len(launches[k]), 1)
     busy, act = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), v.get("GRBM_GUI_ACTIVE", 0.0)
