@@ -276,13 +276,22 @@ def main():
         total.backward()
         return total
 
+    comm = world > 1 or force_comm
+    comm_events = []  # (end of backward, gradients averaged) per step: the EXPOSED part of the gradient exchange
+
     def eager_step():
         reducer.zero_grad()
         total = compute()
-        reducer.finish()
+        if comm:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.finish()
+            e1.record()
+            comm_events.append((e0, e1))
+        else:
+            reducer.finish()
         return total
 
-    comm = world > 1 or force_comm
 
     def fence():
         if comm:
@@ -309,6 +318,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    comm_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -318,6 +328,9 @@ def main():
     if comm:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     elapsed = dt.item()
+    # exposed gradient-exchange time: device time between the last backward kernel and the averaged gradients
+    # (all-reduces that did not finish under the backward pass + the 1/world scaling), rank 0, mean over the timed steps
+    exposed_ms = (sum(a.elapsed_time(b) for a, b in comm_events) / len(comm_events)) if comm_events else None
 
     if graphed is not None:  # the instrumented / side measurements below time individual launches: eager mode
         reducer.defer(False)
@@ -447,6 +460,35 @@ def main():
                              f"({len(boxes_e)} boxes out), no_grad, eval mode"}
         model.train(was_training)
 
+    # Input side: the boundary can also take the decoder's uint8 HWC frames; ToTensor + Normalize are
+    # fused into the stem's gather.  PCIe-inclusive rate of the step when every step first uploads its frames from
+    # pinned host memory: 38.5 MB (uint8) instead of 154 MB (the normalised fp32 tensor).  Never `value`.
+    loader = None
+    if world == 1 and not args.no_exact:
+        u8_host = torch.randint(0, 256, (T, res, res, 3), dtype=torch.uint8).pin_memory()
+        f32_host = torch.empty(T, 3, res, res, dtype=torch.float32).pin_memory()
+        loader = {"h2d_MB_uint8": round(u8_host.numel() / 1e6, 1), "h2d_MB_fp32": round(f32_host.numel() * 4 / 1e6, 1)}
+        for key, host in (("uint8", u8_host), ("fp32", f32_host)):
+            def run_once():
+                dev_frames = host.to(dev, non_blocking=True)
+                reducer.zero_grad()
+                ops.dropout_begin_step(dev)
+                arena.reset()
+                out = model(NestedTensor(dev_frames, mask, [T]), ["synthetic"])
+                losses = criterion(out, targets, [T], plan=plan)
+                total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
+                total.backward()
+                reducer.finish()
+            run_once()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                run_once()
+            fence()
+            loader[f"ms_per_step_with_{key}_h2d"] = round(1e3 * (time.perf_counter() - t1) / 3, 2)
+        loader["note"] = ("frames uploaded from pinned host memory inside every step (PCIe Gen5 x16); uint8 = decoder "
+                          "output [T,H,W,3], normalised inside the stem kernel; fp32 = the reference's normalised [T,3,H,W]")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N=1 only: other ranks would idle at the barrier
         cpu = cpu_baseline(min(args.cpu_sample_frames, T), res, L, T, min(os.cpu_count() or 1, args.cpu_threads))
@@ -457,6 +499,7 @@ def main():
             "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
+            "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
                       "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate",
@@ -468,7 +511,7 @@ def main():
                        "launch": "one hipGraph per step" if args.graph else "eager (launch by launch)",
                        "allreduce_bytes": reducer.message_bytes},
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "other_modes": other_modes,
-            "optimizer_tail": opt_tail, "eval_path": eval_path,
+            "optimizer_tail": opt_tail, "eval_path": eval_path, "input_side": loader,
             "timed_region": "forward + VideoSTGLoss + backward (+ gradient exchange at N > 1); the target-only index "
                             "tensors of the loss (LossPlan) and its 1-element box-count all-reduce "
                             "(criterion.py:175-178) are built once per batch OUTSIDE the timed step (they depend on "

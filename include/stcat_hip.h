@@ -49,6 +49,12 @@ int stcat_frozen_bn_fold(const float* w, const float* b, const float* rm, const 
  * + FrozenBN + ReLU -> NHWC [n,H/2,W/2,64]  (resnet conv1/bn1/relu) */
 int stcat_stem_fwd(const float* frames, const float* w, const float* scale, const float* bias, float* y, int n,
                    int H, int W, void* stream);
+/* The same stem fed by the video decoder's own output: uint8 frames [n,H,W,3] (HWC).  ToTensor + Normalize of the input
+ * pipeline (datasets/vidstg.py:140, datasets/transforms.py:155-168) happen inside the patch gather:
+ * x = u8 * in_scale[c] + in_shift[c] with in_scale = 1 / (255 std), in_shift = -mean / std; padding stays 0 AFTER
+ * normalisation, exactly as conv2d pads the normalised tensor.  4x fewer input bytes, no normalisation pass. */
+int stcat_stem_u8_fwd(const unsigned char* frames_hwc, const float* w, const float* in_scale, const float* in_shift,
+                      const float* scale, const float* bias, float* y, int n, int H, int W, void* stream);
 /* 3x3/2 pad 1 max-pool, NHWC (resnet maxpool) */
 int stcat_maxpool3x3s2(const float* x, float* y, int n, int H, int W, int C, void* stream);
 /* y = relu?(scale*conv(x,w) + bias + res), x NHWC [n,H,W,Cin], w OHWI [Cout,KH,KW,Cin]
@@ -228,6 +234,17 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
                       const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
                       int B, int H, int S, int ldq, int ldk, int ldv, float scale, float drop_p, long drop_seed,
                       long drop_offset, const long* drop_base, void* stream);
+
+/* ---- 2D temporal map head (models/map2d_head.py: Gen2DMap :9-62, TempConvInteraction :228-250) — optional op,
+ *      forward only (the reference defines no loss for it) -------------------------------------------------------- */
+/* adaptive pooling of x [b,T,D] to N steps: T > N: adaptive_avg_pool1d, else adaptive_max_pool1d (:52-55) */
+int stcat_map2d_pool(const float* x, float* pooled, int b, int T, int N, int D, void* stream);
+/* the 39 cascaded MaxPool1d layers written on sparse diagonals (:57-61) in closed form: cell c = (cell_i[c], cell_j[c])
+ * of the caller-zeroed NHWC map [b,N,N,D] = max over pooled[b, cell_i .. cell_j, :] */
+int stcat_map2d_cells(const float* pooled, const int* cell_i, const int* cell_j, int ncells, float* map, int b, int N, int D,
+                      void* stream);
+/* y[m, :] *= w[m % period]: the per-pixel mask-normalisation weight after each conv + ReLU (:247-249) */
+int stcat_rowscale(float* y, const float* w, long rows, int C, int period, void* stream);
 
 /* ---- optimizer tail (scripts/train_net.py:134-143) ------------------------------------------------ */
 /* Multi-tensor launches over a DEVICE table of entries

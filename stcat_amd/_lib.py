@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstcat_hip.so")
 SIGNATURES: Dict[str, str] = {
     "stcat_frozen_bn_fold": "ppppppifs",
     "stcat_stem_fwd": "pppppiiis",
+    "stcat_stem_u8_fwd": "pppppppiiis",
     "stcat_maxpool3x3s2": "ppiiiis",
     "stcat_conv_fwd": "ppppppiiiiiiiiiis",
     "stcat_conv_dgrad": "pppppppppiiiiiiiiis",
@@ -49,6 +50,9 @@ SIGNATURES: Dict[str, str] = {
     "stcat_attn_weights_mean": "ppiii" + "fllps",
     "stcat_attn_q1_fwd": "pppppppp" + "iiiiiif" + "fllps",
     "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "fllps",
+    "stcat_map2d_pool": "ppiiiis",
+    "stcat_map2d_cells": "pppipiiis",
+    "stcat_rowscale": "pplii" + "s",
     "stcat_grad_sqnorm": "pppiips",
     "stcat_adamw_ema_step": "pppiipPPifffiffs",
     "stcat_grad_clip_scale": "pppiipfs",

@@ -99,6 +99,14 @@ def _ohwi(w: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
+def _stem(frames, body, s, b):
+    """fp32 [n,3,H,W] (the reference's normalised NestedTensor) or uint8 [n,H,W,3] straight from the decoder: the
+    uint8 form folds ToTensor + Normalize into the stem's gather."""
+    if frames.dtype == torch.uint8:
+        return ops.stem_u8_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+    return ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+
+
 class _BackboneFn(Function):
     """frames [n,3,H,W] (NCHW, as handed over by the data pipeline) -> layer4 features NHWC [n,H/32,W/32,2048]."""
 
@@ -106,7 +114,7 @@ class _BackboneFn(Function):
     def forward(ctx, frames, body: ResNet101Body, *weights):
         need_bwd = any(w.requires_grad for w in weights)
         s, b = body.bn1.folded()
-        x = ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+        x = _stem(frames, body, s, b)
         x = ops.maxpool_raw(x)
         tape = []
         for li, blk in body.blocks():
@@ -185,7 +193,7 @@ class _BackboneFnPl(Function):
     def forward(ctx, frames, body: ResNet101Body, *weights):
         need_bwd = any(w.requires_grad for w in weights)
         s, b = body.bn1.folded()
-        x = ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+        x = _stem(frames, body, s, b)
         x = ops.pl_maxpool_raw(x)
         blocks = list(body.blocks())
         ws = []

@@ -439,6 +439,11 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(IgemmParams p) {
 // either operand); the frame tensor is read straight from its [T,3,H,W] layout.
 // ---------------------------------------------------------------------------------
 #define STCAT_STEM_KMAX 160  // 3 * 7 * 7 = 147 reduction rows, padded to whole K-tiles of 16
+// U8 = true: the frames arrive as the video decoder leaves them — uint8 [n][H][W][3] (HWC) — and the input pipeline's
+// ToTensor + Normalize (datasets/vidstg.py:140, datasets/transforms.py:155-168: (x / 255 - mean[c]) / std[c]) is applied
+// inside the gather: a quarter of the input bytes of the fp32 [n,3,H,W] tensor (38.5 MB instead of 154 MB at C3), no
+// separate normalisation pass.  p.scale2u = 1 / (255 std[c]), p.shift2u = -mean[c] / std[c] ride in p.mscale / p.c2scale.
+template <bool U8>
 __global__ void __launch_bounds__(256) igemm_stem_kernel(IgemmParams p) {
   constexpr int BM = 128, BN = 64, BK = 16, LDA = BM + 4, LDBS = BN + 4, TM = 2, TN = 1;
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
@@ -473,18 +478,23 @@ __global__ void __launch_bounds__(256) igemm_stem_kernel(IgemmParams p) {
   // (ci, kh, kw) of a reduction index depend on the index alone: decode all <= 160 of them once per workgroup
   // (the per-element divisions were ~60 VALU ops each and made the kernel index-math-bound)
   __shared__ int tdh[STCAT_STEM_KMAX], tdw[STCAT_STEM_KMAX], toff[STCAT_STEM_KMAX];
+  __shared__ float tsc[STCAT_STEM_KMAX], tsh[STCAT_STEM_KMAX];
   if (t < STCAT_STEM_KMAX) {
     int dh = 1 << 20, dw_ = 0, off = 0;  // rows past K: forced out of range -> zero fill
+    float sc_ = 0.f, sh_ = 0.f;
     if (t < p.K) {
       const int ci = t / khw, rem = t - ci * khw;
       dh = rem / g.KW;
       dw_ = rem - dh * g.KW;
-      off = (ci * g.H + dh) * g.W + dw_;
+      off = U8 ? (dh * g.W + dw_) * g.C + ci : (ci * g.H + dh) * g.W + dw_;
+      if (U8) { sc_ = p.mscale[ci]; sh_ = p.c2scale[ci]; }
     }
-    tdh[t] = dh; tdw[t] = dw_; toff[t] = off;
+    tdh[t] = dh; tdw[t] = dw_; toff[t] = off; tsc[t] = sc_; tsh[t] = sh_;
   }
   __syncthreads();
-  const long abase = ((long)nb * g.C * g.H + bh) * g.W + bw;  // + toff[r] = ((nb*C + ci)*H + bh + kh)*W + bw + kw
+  // fp32 NCHW: + toff[r] = ((nb*C + ci)*H + bh + kh)*W + bw + kw;  uint8 HWC: ((nb*H + bh + kh)*W + bw + kw)*C + ci
+  const long abase = U8 ? (((long)nb * g.H + bh) * g.W + bw) * g.C : ((long)nb * g.C * g.H + bh) * g.W + bw;
+  const unsigned char* A8 = reinterpret_cast<const unsigned char*>(p.A);
 #define STCAT_STEM_LOAD(KT)                                                              \
   {                                                                                      \
     STCAT_UNROLL                                                                         \
@@ -492,7 +502,8 @@ __global__ void __launch_bounds__(256) igemm_stem_kernel(IgemmParams p) {
       const int r = (KT) * BK + ak + e;                                                  \
       const int h = bh + tdh[r], w = bw + tdw[r];                                        \
       float val = 0.f;                                                                   \
-      if (nb >= 0 && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) val = p.A[abase + toff[r]]; \
+      if (nb >= 0 && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W)                         \
+        val = U8 ? (float)A8[abase + toff[r]] * tsc[r] + tsh[r] : p.A[abase + toff[r]];                  \
       ra[e] = val;                                                                       \
     }                                                                                    \
     STCAT_UNROLL                                                                         \

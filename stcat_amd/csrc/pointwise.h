@@ -450,3 +450,58 @@ __global__ void __launch_bounds__(256) weight_transpose_multi_kernel(const WtEnt
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------
+// 2D temporal map head (models/map2d_head.py) — optional op, forward only (the reference never wires it into a loss).
+// Gen2DMap (:9-62) = adaptive pooling of the T frame features to N steps, then 39 cascaded MaxPool1d layers written on
+// sparse diagonals.  In closed form every valid cell (i, j) holds the RANGE MAXIMUM of the pooled sequence over [i, j]
+// (verified equal to the cascade, tests/golden/map2d.npz), so the cascade becomes two small kernels.
+// ---------------------------------------------------------------------------------------------------
+// x [b][T][D] -> pooled [b][N][D]:  T > N: adaptive_avg_pool1d (then adaptive_max_pool1d N -> N = identity);
+//                                   T <= N: adaptive_max_pool1d.  Window of step n: [floor(n T / N), ceil((n+1) T / N))
+__global__ void __launch_bounds__(256) map2d_pool_kernel(const float* x, float* pooled, int b, int T, int N, int D) {
+  const long total = (long)b * N * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D), n = (int)((i / D) % N), bb = (int)(i / ((long)D * N));
+    const int s = (n * T) / N, e = ((n + 1) * T + N - 1) / N;
+    const float* src = x + ((long)bb * T) * D + d;
+    float acc = T > N ? 0.f : STCAT_NEG_INF;
+    for (int t = s; t < e; ++t) {
+      const float v = src[(long)t * D];
+      acc = T > N ? acc + v : fmaxf(acc, v);
+    }
+    pooled[i] = T > N ? acc / (float)(e - s) : acc;
+  }
+}
+
+// pooled [b][N][D] -> map NHWC [b][N][N][D]: cell c of the sparse list -> (ci[c], cj[c]); the rest of the map is zero
+// (caller-zeroed).  One thread per (batch, cell, 4 channels).
+__global__ void __launch_bounds__(256) map2d_cells_kernel(const float* pooled, const int* ci, const int* cj, int ncells,
+                                                         float* map, int b, int N, int D) {
+  const int d4n = D / 4;
+  const long total = (long)b * ncells * d4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % d4n), c = (int)((i / d4n) % ncells), bb = (int)(i / ((long)d4n * ncells));
+    const int i0 = ci[c], j0 = cj[c];
+    float4 m = make_float4(STCAT_NEG_INF, STCAT_NEG_INF, STCAT_NEG_INF, STCAT_NEG_INF);
+    for (int n = i0; n <= j0; ++n) {
+      const float4 v = stcat_ld4(pooled + ((long)bb * N + n) * D + d4 * 4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    stcat_st4(map + (((long)bb * N + i0) * N + j0) * D + d4 * 4, m);
+  }
+}
+
+// y[m][:] *= w[m % period]  — the mask-normalisation weight of TempConvInteraction (:245-249): one factor per map pixel
+__global__ void __launch_bounds__(256) rowscale_kernel(float* y, const float* w, long rows, int C, int period) {
+  const int c4n = C / 4;
+  const long total = rows * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n;
+    const float f = w[m % period];
+    float4 v = stcat_ld4(y + i * 4);
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    stcat_st4(y + i * 4, v);
+  }
+}

@@ -429,7 +429,22 @@ int stcat_stem_fwd(const float* frames, const float* w, const float* scale, cons
   p.M = n * OH * OW; p.N = 64; p.K = 147; p.ldb = 147; p.ldc = 64; p.ldr = 0;
   p.c_group = p.M; p.c_group_stride = 0; p.relu = 1;
   p.g = conv_geom_fwd(H, W, 3, 0, OH, OW, 7, 7, 2, 3);
-  STCAT_LAUNCH(igemm_stem_kernel, dim3(cdiv(p.M, 128)), dim3(256), 0, (hipStream_t)stream, p);
+  STCAT_LAUNCH(igemm_stem_kernel<false>, dim3(cdiv(p.M, 128)), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+int stcat_stem_u8_fwd(const unsigned char* frames_hwc, const float* w, const float* in_scale, const float* in_shift,
+                      const float* scale, const float* bias, float* y, int n, int H, int W, void* stream) {
+  if (n <= 0 || H < 7 || W < 7) return fail("stem_u8_fwd: bad shape n=%d H=%d W=%d", n, H, W);
+  if (!in_scale || !in_shift) return fail("stem_u8_fwd: the per-channel input scale / shift are required");
+  const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  IgemmParams p = {};
+  p.A = reinterpret_cast<const float*>(frames_hwc); p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = nullptr;
+  p.mscale = in_scale; p.c2scale = in_shift;
+  p.M = n * OH * OW; p.N = 64; p.K = 147; p.ldb = 147; p.ldc = 64; p.ldr = 0;
+  p.c_group = p.M; p.c_group_stride = 0; p.relu = 1;
+  p.g = conv_geom_fwd(H, W, 3, 0, OH, OW, 7, 7, 2, 3);
+  STCAT_LAUNCH(igemm_stem_kernel<true>, dim3(cdiv(p.M, 128)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 
@@ -982,6 +997,28 @@ int stcat_mha_bs_bwd(const float* q, const float* k, const float* v, const unsig
     if (int rc = pl_prepare(mha_bs_bwd_kernel<NW>, lds)) return rc;
     STCAT_LAUNCH((mha_bs_bwd_kernel<NW>), dim3(B * H), dim3(64 * NW), lds, st, p, out);
   })
+  return launch_status();
+}
+
+// ---- 2D temporal map head (models/map2d_head.py), optional op, forward only -------------------------------------
+int stcat_map2d_pool(const float* x, float* pooled, int b, int T, int N, int D, void* stream) {
+  if (b <= 0 || T <= 0 || N <= 0 || D <= 0) return fail("map2d_pool: bad shape");
+  STCAT_LAUNCH(map2d_pool_kernel, dim3(grid_for((long)b * N * D, 256)), dim3(256), 0, (hipStream_t)stream, x, pooled, b, T,
+               N, D);
+  return launch_status();
+}
+
+int stcat_map2d_cells(const float* pooled, const int* cell_i, const int* cell_j, int ncells, float* map, int b, int N, int D,
+                      void* stream) {
+  if (D % 4 != 0 || ncells <= 0) return fail("map2d_cells: D %% 4 != 0 or no cells");
+  STCAT_LAUNCH(map2d_cells_kernel, dim3(grid_for((long)b * ncells * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+               pooled, cell_i, cell_j, ncells, map, b, N, D);
+  return launch_status();
+}
+
+int stcat_rowscale(float* y, const float* w, long rows, int C, int period, void* stream) {
+  if (C % 4 != 0 || rows <= 0 || period <= 0) return fail("rowscale: bad shape");
+  STCAT_LAUNCH(rowscale_kernel, dim3(grid_for(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, y, w, rows, C, period);
   return launch_status();
 }
 

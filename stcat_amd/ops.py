@@ -918,6 +918,28 @@ def stem_fwd_raw(frames, w_oihw, scale, bias):
     return y
 
 
+PIXEL_MEAN, PIXEL_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)  # cfg.INPUT.PIXEL_MEAN / PIXEL_STD of both experiment files
+_U8_NORM = {}
+
+
+def stem_u8_fwd_raw(frames_u8_hwc, w_oihw, scale, bias, mean=PIXEL_MEAN, std=PIXEL_STD):
+    """uint8 [n,H,W,3] decoder frames -> stem output NHWC fp32; ToTensor + Normalize fused into the gather
+    (datasets/vidstg.py:140, datasets/transforms.py:155-168)."""
+    n, H, W, C = frames_u8_hwc.shape
+    assert C == 3 and frames_u8_hwc.dtype == torch.uint8 and frames_u8_hwc.is_contiguous()
+    L.check_tensor(frames_u8_hwc)
+    key = (str(frames_u8_hwc.device), tuple(mean), tuple(std))
+    if key not in _U8_NORM:
+        m, s_ = torch.tensor(mean, dtype=torch.float64), torch.tensor(std, dtype=torch.float64)
+        _U8_NORM[key] = ((1.0 / (255.0 * s_)).float().to(frames_u8_hwc.device), (-m / s_).float().to(frames_u8_hwc.device))
+    isc, ish = _U8_NORM[key]
+    OH, OW = conv_out_hw(H, W, 7, 2, 3)
+    y = torch.empty(n, OH, OW, 64, device=frames_u8_hwc.device, dtype=_f32)
+    L.call("stcat_stem_u8_fwd", frames_u8_hwc.data_ptr(), w_oihw.data_ptr(), isc.data_ptr(), ish.data_ptr(),
+           scale.data_ptr(), bias.data_ptr(), y.data_ptr(), n, H, W, L.stream_of(frames_u8_hwc))
+    return y
+
+
 def maxpool_raw(x):
     n, H, W, C = x.shape
     OH, OW = conv_out_hw(H, W, 3, 2, 1)

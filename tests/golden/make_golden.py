@@ -412,8 +412,54 @@ def eval_vectors():
     return g
 
 
+MAP2D_CFG = dict(MAX_MAP_SIZE=32, POOLING_COUNTS=[7, 4, 4], HIDDEN=64, HEADS=8, FFN_DIM=128, DROPOUT=0.1,
+                 TEMP_PRED_LAYERS=2, TEMP_HEAD="conv", KERNAL_SIZE=3, CONV_LAYERS=2)
+
+
+def map2d_vectors():
+    """Known answers of models/map2d_head.py (Gen2DMap :9-62, TempPredictionHead 'conv' :65-127, TempConvInteraction
+    :228-250) at a small configuration.  The reference hard-codes .to("cuda") (:33): patched to "cpu" for this run, as
+    SURVEY.md §8c prescribes; the MODEL.TEMPFORMER config node does not exist in the reference's config and is supplied."""
+    import importlib.util
+    from types import SimpleNamespace as NS
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        return orig_to(self, *tuple("cpu" if (isinstance(x, str) and x == "cuda") else x for x in a), **k)
+    torch.Tensor.to = to_cpu
+    try:
+        spec = importlib.util.spec_from_file_location("ref_map2d_head", os.path.join(REF, "models", "map2d_head.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        cfg = NS(MODEL=NS(TEMPFORMER=NS(**MAP2D_CFG)))
+        g = {}
+        gen = m.Gen2DMap(cfg)
+        g["map2d/mask"] = gen.mask2d.numpy()
+        for tag, T in (("short", 20), ("long", 40)):     # T < N: adaptive max only; T > N: adaptive avg then max
+            x = torch.from_numpy(synth.hash_normal(f"op/map2d/x{T}", 2 * T * 64).reshape(2, T, 64))
+            g[f"map2d/{tag}/x"] = x.numpy()
+            g[f"map2d/{tag}/map"] = gen(x).numpy()      # [b, d, N, N]
+        head = m.TempPredictionHead(cfg).eval()
+        with torch.no_grad():
+            for k, v in head.state_dict().items():
+                v.copy_(torch.from_numpy(synth.synth_value("map2d_head." + k, tuple(v.shape))))
+            for i, w in enumerate(head.encoder.weights):
+                g[f"map2d/weight{i}"] = w.numpy()
+            xh = torch.from_numpy(synth.hash_normal("op/map2d/xh", 2 * 1 * 20 * 64).reshape(2, 1, 20, 64))
+            g["map2d/head/x"] = xh.numpy()
+            g["map2d/head/scores"] = head(xh).numpy()     # eval: sigmoid(scores) * mask  [layers, b, N, N]
+        g["map2d/head/keys"] = np.array(list(head.state_dict().keys()))
+    finally:
+        torch.Tensor.to = orig_to
+    return g
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    if sys.argv[1:] == ["map2d"]:
+        np.savez_compressed(os.path.join(out_dir, "map2d.npz"), **map2d_vectors())
+        print("map2d.npz written")
+        return
     if sys.argv[1:] == ["eval"]:
         np.savez_compressed(os.path.join(out_dir, "eval.npz"), **eval_vectors())
         print("eval.npz written")

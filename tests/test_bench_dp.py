@@ -39,12 +39,13 @@ def test_bench_rccl_path_single_rank_and_json_is_last_line():
     env = dict(os.environ, STCAT_FORCE_COMM="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     env.pop("STCAT_DIST_BACKEND", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "C1",
-           "--no-cpu-baseline", "--no-exact", "--no-optim"]
+           "--no-cpu-baseline", "--no-exact", "--no-optim", "--roberta-dummy"]   # reference-sized message: 824 MB
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     last = [l for l in r.stdout.splitlines() if l.strip()][-1]
     d = json.loads(last)                       # raises if anything (e.g. the RCCL banner) follows the line
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["allreduce_bytes"] > 3e8
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["allreduce_bytes"] > 8.2e8
+    assert d["exposed_comm_ms_per_step"] is not None and d["exposed_comm_ms_per_step"] >= 0
 
 
 @pytest.mark.gpu

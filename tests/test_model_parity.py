@@ -383,6 +383,32 @@ def test_gpu_c5_shaped_clip_forward():
 
 
 @pytest.mark.gpu
+def test_gpu_uint8_frames_through_the_model():
+    """the model fed with the decoder's uint8 [T,H,W,3] frames (ToTensor + Normalize fused into the
+    stem gather, datasets/transforms.py:155-168) gives the outputs of the fp32 path on the normalised [T,3,H,W] tensor."""
+    from stcat_amd import _lib, ops
+    dev = use_hip()
+    T, res, L = 8, 224, 10
+    _lib.set_mma_mode(BENCH_MMA)
+    try:
+        model, _, _ = build_model(None, SyntheticText(synth.synth_text(L)))
+        model.eval()
+        synth.fill_module_(model)
+        model.to(dev)
+        u8 = torch.randint(0, 256, (T, res, res, 3), generator=torch.Generator().manual_seed(5), dtype=torch.uint8)
+        mean, std = torch.tensor(ops.PIXEL_MEAN), torch.tensor(ops.PIXEL_STD)
+        f32 = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
+        mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+        with torch.no_grad():
+            o8 = model(NestedTensor(u8.to(dev), mask, [T]), ["q"])
+            of = model(NestedTensor(f32.to(dev), mask, [T]), ["q"])
+    finally:
+        _lib.set_mma_mode("f32")
+    for k in ("pred_boxes", "pred_sted", "pred_actioness"):
+        close(o8[k], of[k], 1e-4, "uint8 input " + k, absolute=True)
+
+
+@pytest.mark.gpu
 def test_gpu_two_pass_eval_path():
     """engine/evaluate.py:97-119: even/odd frame halves evaluated separately, spans united."""
     from stcat_amd.pipeline import evaluate_video

@@ -245,6 +245,23 @@ def _pl_maxpool(dev, big):
 
 
 @both
+def _stem_uint8_loader(dev, big):
+    """uint8 HWC frames -> stem with ToTensor + Normalize fused into the gather == the fp32 path on the normalised
+    NCHW tensor (datasets/vidstg.py:140, transforms.py:155-168), and == conv2d of the normalised tensor."""
+    n, H, W = (2, 20, 26) if not big else (4, 224, 224)
+    u8 = torch.randint(0, 256, (n, H, W, 3), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    mean, std = torch.tensor(ops.PIXEL_MEAN), torch.tensor(ops.PIXEL_STD)
+    x = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()       # ToTensor + Normalize, NCHW
+    w = rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5)
+    scale, bias = rnd(64, seed=3).abs() + 0.5, rnd(64, seed=4)
+    ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    y8 = ops.stem_u8_fwd_raw(u8.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+    yf = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+    close(y8.permute(0, 3, 1, 2), ref, TOL, "uint8 stem vs conv2d of the normalised tensor")
+    close(y8, yf, 2e-5, "uint8 stem vs fp32 stem")
+
+
+@both
 def _stem_pool(dev, big):
     n, H = (2, 20) if not big else (4, 224)
     x = rnd(n, 3, H, H, seed=1)
