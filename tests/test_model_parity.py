@@ -449,4 +449,6 @@ def test_gpu_two_pass_eval_path():
     merged = {f: [[float(v) for v in boxes[(0, ids[0][k])].double().cpu()]] for k, f in enumerate(gap_ids[0])}
     want = O.linear_interp(merged)
     for f in range(100, 116):
-        close(dense[(0, f)], torch.tensor(want[f][0], dtype=torch.float64), 1e-9, f"interpolated box {f}")
+        # (two separate runs of the model: split-K launches add partial sums in arrival order, so the given frames
+        # themselves agree to fp32 round-off, not bitwise)
+        close(dense[(0, f)], torch.tensor(want[f][0], dtype=torch.float64), 2e-5, f"interpolated box {f}")
