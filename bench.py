@@ -56,7 +56,7 @@ def _flops(name, a):
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin
     if name in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad", "stcat_pl_conv_wgrad"):
-        o = {"stcat_pl_conv_fwd": 12, "stcat_pl_conv_dgrad": 15, "stcat_pl_conv_wgrad": 5}[name]
+        o = {"stcat_pl_conv_fwd": 12, "stcat_pl_conv_dgrad": 15, "stcat_pl_conv_wgrad": 6}[name]
         n, H, W, Cin, Cout, KH, KW, stride, pad = a[o:o + 9]
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         return 2.0 * n * OH * OW * Cout * KH * KW * Cin

@@ -108,9 +108,10 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
                         const float* mask_scale, void* dxh, void* dxl,
                         void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, void* stream);
-/* dw (fp32 OHWI, caller-zeroed) += sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0 */
-int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, int n, int H, int W,
-                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* dw (fp32 OHWI, caller-zeroed) += row_scale[co] * sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0.
+ * row_scale (optional, [Cout]): a FrozenBN scale folded out of g — dz * scale is never materialised */
+int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
+                        int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* resnet maxpool 3x3/2 pad 1: fp32 NHWC in (stem output) -> planes out */
 int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int W, int C, void* stream);
 /* fp32 <-> planes; n % 8 == 0 */
@@ -123,9 +124,9 @@ int stcat_pl_act_bwd(const float* dy, const float* y, const float* scale, void* 
 /* g = x * scale[c] on planes (upstream gradient of a downsample conv: dz * FrozenBN scale) */
 int stcat_pl_scale(const void* xh, const void* xl, const float* scale, void* gh, void* gl, long n, int C, void* stream);
 /* weight planes for many conv weights in ONE launch: DEVICE table of entries
- *   { const float* w; bf16* wh, *wl, *th, *tl; int Cout, taps, Cin; int blk0, nbx, nby; int pad; }
- * (stcat_weight_planes_entry_bytes() == 72): w fp32 OHWI -> (wh, wl) OHWI planes and, when th != NULL, the transposed
- * planes (th, tl) [taps][Cin][Cout]; entry e owns grid blocks [blk0, blk0 + nbx*nby*taps), nbx = ceil(Cin/32),
+ *   { const float* w; bf16* wh, *wl, *th, *tl; const float* tscale; int Cout, taps, Cin; int blk0, nbx, nby; int pad; }
+ * (stcat_weight_planes_entry_bytes() == 80): w fp32 OHWI -> (wh, wl) OHWI planes and, when th != NULL, the transposed
+ * planes (th, tl) [taps][Cin][Cout] of w * tscale[co] (tscale optional); entry e owns grid blocks [blk0, blk0 + nbx*nby*taps), nbx = ceil(Cin/32),
  * nby = ceil(Cout/32), blk0 ascending */
 int stcat_weight_planes_entry_bytes(void);
 int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream);

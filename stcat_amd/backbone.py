@@ -196,12 +196,17 @@ class _BackboneFnPl(Function):
         x = _stem(frames, body, s, b)
         x = ops.pl_maxpool_raw(x)
         blocks = list(body.blocks())
-        ws = []
+        # conv3 / downsample are followed by a FrozenBN and the block's ReLU: their upstream gradient is dz * scale.
+        # The scale is folded into the transposed weight planes (data gradient) and into the weight-gradient epilogue,
+        # so the backward pass works on dz alone and never writes a second, scaled copy of it.
+        ws, ts = [], []
         for _, blk in blocks:
             ws += [_ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)]
+            ts += [None, None, blk.bn3.folded()[0]]
             if blk.downsample is not None:
                 ws.append(_ohwi(blk.downsample[0].weight))
-        wp, wt = body._wpl_cache.refresh(ws, transposed=need_bwd)
+                ts.append(blk.downsample[1].folded()[0])
+        wp, wt = body._wpl_cache.refresh(ws, transposed=need_bwd, tscales=ts)
         tape = []
         yf = None
         for bi, (li, blk) in enumerate(blocks):
@@ -245,35 +250,34 @@ class _BackboneFnPl(Function):
         # workgroups run on the CUs the data-gradient launch leaves idle.
         wg = ops.WgradStream(dy)
 
-        def wgrad(key, g, xin, wshape, stride, pad):
+        def wgrad(key, g, xin, wshape, stride, pad, row_scale=None):
             with wg:
-                grads[key] = ops.pl_conv_wgrad_raw(g, xin, wshape, stride, pad)
+                grads[key] = ops.pl_conv_wgrad_raw(g, xin, wshape, stride, pad, row_scale)
             wg.keep(g, xin)
 
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
-        # top of the stack (y is the fp32 layer4 output): dz = dy * [y > 0], g3 = dz * scale3 — both as planes
-        g3, dz = ops.pl_act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
+        # top of the stack (y is the fp32 layer4 output): dz = dy * [y > 0] as planes
+        _, dz = ops.pl_act_bwd_raw(dy.contiguous(), y, None, want_g=False, want_res=True, relu=True)
         for idx in range(len(tape) - 1, -1, -1):
             blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd) = tape[idx]
             need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
-            wgrad(id(blk.conv3.weight), g3, o2, w3.shape, 1, 0)
-            g2 = ops.pl_conv_dgrad_raw(g3, _wt(w3), o2.shape, 1, 1, 0, mask_y=o2, mask_scale=s2)
+            # conv3 (and the downsample conv) see dz directly: their FrozenBN scale sits in the transposed weight
+            # planes and in the weight-gradient epilogue
+            wgrad(id(blk.conv3.weight), dz, o2, w3.shape, 1, 0, s3)
+            g2 = ops.pl_conv_dgrad_raw(dz, _wt(w3), o2.shape, 1, 1, 0, mask_y=o2, mask_scale=s2)
             wgrad(id(blk.conv2.weight), g2, o1, w2.shape, blk.stride, 1)
             g1 = ops.pl_conv_dgrad_raw(g2, _wt(w2), o1.shape, 3, blk.stride, 1, mask_y=o1, mask_scale=s1)
             wgrad(id(blk.conv1.weight), g1, x, w1.shape, 1, 0)
-            gd = None
             if wd is not None:
-                gd = ops.pl_scale_raw(dz, sd)  # dz * scale_downsample
-                wgrad(id(blk.downsample[0].weight), gd, x, wd.shape, blk.stride, 0)
+                wgrad(id(blk.downsample[0].weight), dz, x, wd.shape, blk.stride, 0, sd)
             if not need_dx:
                 break
-            s3_below = tape[idx - 1][6][2]
+            # block boundary: x is the ReLU output of the block below; its dz comes out of this epilogue
             if wd is not None:
-                part = ops.pl_conv_dgrad_raw(gd, _wt(wd), x.shape, 1, blk.stride, 0)
-                dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=part, out=part, mask_y=x,
-                                               scale2=s3_below)
+                part = ops.pl_conv_dgrad_raw(dz, _wt(wd), x.shape, 1, blk.stride, 0)
+                dz = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=part, out=part, mask_y=x)
             else:
-                dz, g3 = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=dz, mask_y=x, scale2=s3_below)
+                dz = ops.pl_conv_dgrad_raw(g1, _wt(w1), x.shape, 1, 1, 0, add=dz, mask_y=x)
         wg.join(*grads.values())
         out = []
         for w in ctx.plist:

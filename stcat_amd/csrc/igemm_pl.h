@@ -47,6 +47,7 @@ struct PlParams {
   unsigned b_tap_stride;                // elements
   int k_chunk;                          // wgrad: pixels of the reduction per grid.z slice (multiple of 32)
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
+  const float* wscale;                  // wgrad: optional per-row factor dW[m][:] *= wscale[m] (a FrozenBN scale folded out of dY)
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
                                         // 2 = epilogue without global loads / stores
   IgemmGeom g;
@@ -479,7 +480,8 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       STCAT_UNROLL
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (!((p.debug & 1) && acc[tm][tn][r] != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], acc[tm][tn][r]);
+        const float v_ = p.wscale ? acc[tm][tn][r] * p.wscale[m] : acc[tm][tn][r];
+        if (!((p.debug & 1) && v_ != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], v_);
       }
     }
   }
@@ -577,6 +579,8 @@ __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
 struct WplEntry {
   const float* w;
   __bf16* wh; __bf16* wl; __bf16* th; __bf16* tl;
+  const float* tscale;   // optional [Cout]: the transposed planes hold w * tscale[co] (a FrozenBN scale folded into the
+                         // data-gradient operand, so the upstream gradient dz * scale never has to be materialised)
   int Cout, taps, Cin;
   int blk0, nbx, nby;
   int pad_;
@@ -603,7 +607,7 @@ __global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry
       e.wh[idx] = h;
       e.wl[idx] = (__bf16)(x - (float)h);
     }
-    tile[r][tx] = x;
+    tile[r][tx] = (e.tscale && co < e.Cout) ? x * e.tscale[co] : x;
   }
   if (!e.th) return;
   __syncthreads();

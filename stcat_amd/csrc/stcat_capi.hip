@@ -880,12 +880,12 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
   return launch_pl_fwd(p, (hipStream_t)stream);
 }
 
-int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, int n, int H, int W,
-                        int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
+                        int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   PlParams p = {};
   p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)xh; p.Bl = (const __bf16*)xl;
-  p.Wf = dw; p.ldb = Cout; p.ldc = KH * KW * Cin;
+  p.Wf = dw; p.wscale = row_scale; p.ldb = Cout; p.ldc = KH * KW * Cin;
   p.a_bytes = plane_bytes((long)n * OH * OW * Cout); p.b_bytes = plane_bytes((long)n * H * W * Cin);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_wgrad: a plane exceeds 2 GB");
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);

@@ -1065,12 +1065,13 @@ def pl_conv_dgrad_raw(g: Planes, wt: Planes, in_shape, k, stride, pad, add: Opti
     return dx if scale2 is None else (dx, dx2)
 
 
-def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad) -> torch.Tensor:
+def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad, row_scale=None) -> torch.Tensor:
+    """row_scale [Cout]: dW[co] *= row_scale[co] — a FrozenBN scale folded out of g (g = dz, not dz * scale)"""
     n, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape_ohwi
     dw = _zeros(g.t, Cout, KH, KW, Cin)
-    L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), n, H, W, Cin, Cout, KH, KW, stride, pad,
-           L.stream_of(g.t))
+    L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), L._ptr(row_scale), n, H, W, Cin, Cout, KH, KW,
+           stride, pad, L.stream_of(g.t))
     return dw
 
 
@@ -1104,15 +1105,18 @@ class WeightPlanes:
         self.total = 0
         self.n = 0
 
-    def refresh(self, weights, transposed: bool):
-        """weights: list of OHWI fp32 tensors; returns ({ptr: Planes fwd}, {ptr: Planes transposed})"""
+    def refresh(self, weights, transposed: bool, tscales=None):
+        """weights: list of OHWI fp32 tensors; tscales: optional list (one entry per weight, None = 1) of [Cout] factors
+        folded into the TRANSPOSED planes; returns ({ptr: Planes fwd}, {ptr: Planes transposed})"""
         import numpy as np
-        key = (tuple(w.data_ptr() for w in weights), bool(transposed) or bool(self.tr))
+        tscales = tscales if tscales is not None else [None] * len(weights)
+        key = (tuple(w.data_ptr() for w in weights), bool(transposed) or bool(self.tr),
+               tuple(0 if t is None else t.data_ptr() for t in tscales))
         if key != self.key:
             want_tr = key[1]
-            dt = np.dtype([("w", "<u8"), ("wh", "<u8"), ("wl", "<u8"), ("th", "<u8"), ("tl", "<u8"), ("Cout", "<i4"),
-                           ("taps", "<i4"), ("Cin", "<i4"), ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4"),
-                           ("pad", "<i4"), ("pad2", "<i4")])
+            dt = np.dtype([("w", "<u8"), ("wh", "<u8"), ("wl", "<u8"), ("th", "<u8"), ("tl", "<u8"), ("tscale", "<u8"),
+                           ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"), ("blk0", "<i4"), ("nbx", "<i4"),
+                           ("nby", "<i4"), ("pad", "<i4"), ("pad2", "<i4")])
             assert dt.itemsize == L.load().stcat_weight_planes_entry_bytes(), dt.itemsize
             tab = np.zeros(len(weights), dtype=dt)
             self.fwd, self.tr, blk = {}, {}, 0
@@ -1127,7 +1131,8 @@ class WeightPlanes:
                     self.tr[w.data_ptr()] = tp
                     th, tl = tp.h, tp.l
                 nbx, nby = (Cin + 31) // 32, (Cout + 31) // 32
-                tab[i] = (w.data_ptr(), wp.h, wp.l, th, tl, Cout, taps, Cin, blk, nbx, nby, 0, 0)
+                ts = tscales[i].data_ptr() if (want_tr and tscales[i] is not None) else 0
+                tab[i] = (w.data_ptr(), wp.h, wp.l, th, tl, ts, Cout, taps, Cin, blk, nbx, nby, 0, 0)
                 blk += nbx * nby * taps
             self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(weights[0].device)
             self.total, self.key, self.n, self.state = blk, key, len(weights), None

@@ -197,6 +197,14 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
         dx4, dx5 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, add=dx, mask_y=ymp, scale2=msc)  # bit-mask form
         dw = ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad) if wgrad else None
         gs = ops.pl_scale_raw(G, msc[:1].expand(Cout).contiguous())
+        # FrozenBN scale folded into the transposed planes / the weight-gradient epilogue == running on g * scale
+        fsc = torch.rand(Cout, device=dev) + 0.5
+        _, wts = ops.WeightPlanes().refresh([wd], transposed=True, tscales=[fsc])
+        Gs = ops.pl_scale_raw(G, fsc)
+        dx_fold = ops.pl_conv_dgrad_raw(G, wts[wd.data_ptr()], xd.shape, k, stride, pad)
+        dx_ref = ops.pl_conv_dgrad_raw(Gs, wt, xd.shape, k, stride, pad)
+        dw_fold = ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad, row_scale=fsc).clone() if wgrad else None
+        dw_sref = ops.pl_conv_wgrad_raw(Gs, xp, wd.shape, stride, pad).clone() if wgrad else None
     finally:
         L.call("stcat_debug_force_pl_tile", -1)
     tag = f"plane conv {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
@@ -209,6 +217,9 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
     close(ops.pl_join(dx4), ref4, TOL, tag + " dgrad boundary dz")
     close(ops.pl_join(dx5), ref4 * msc.cpu(), TOL, tag + " dgrad boundary dz*scale")
     close(ops.pl_join(gs), ops.pl_join(G).cpu() * msc[:1].cpu(), 2e-5, tag + " plane scale")
+    close(ops.pl_join(dx_fold), ops.pl_join(dx_ref), 5e-5, tag + " dgrad with the scale folded into the weight planes")
+    if wgrad:
+        close(dw_fold, dw_sref, 5e-5, tag + " wgrad with the scale folded into the epilogue")
     if wgrad:
         close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
     if res:

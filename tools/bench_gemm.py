@@ -89,7 +89,7 @@ def main():
                 dw = torch.zeros_like(w)
 
                 def wgp():
-                    L.call("stcat_pl_conv_wgrad", gp.h, gp.l, xp.h, xp.l, dw.data_ptr(), n, H, W, Cin, Cout, k, k, stride,
+                    L.call("stcat_pl_conv_wgrad", gp.h, gp.l, xp.h, xp.l, dw.data_ptr(), None, n, H, W, Cin, Cout, k, k, stride,
                            pad, L.stream_of(x))
                 t_w = timeit(wgp)
             for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
