@@ -78,24 +78,32 @@ def _flops(name, a):
 
 
 def _pmc_traffic(entry: str, mma: str):
-    """HBM bytes per launch of the dominant entry point's kernels, from the committed rocprofv3 PMC passes of this
-    same command (profiles/*hbm_traffic*.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, x1024, reads
-    x2 per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read from inside the process, hence the file."""
+    """HBM bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes of this same command
+    (profiles/*hbm_traffic*<mode>*.json: FETCH_SIZE / WRITE_SIZE collected in separate passes, x1024, reads x2 per
+    MI355X_MICROARCH.md §HBM).  PMC counters cannot be read from inside the process, hence the file."""
     import glob
-    fam = {"stcat_conv_fwd": "_fwd_kernel", "stcat_conv_dgrad": "_dgrad_kernel", "stcat_conv_wgrad": "_wgrad_kernel"}.get(entry)
-    if entry.startswith("igemm_bs_fwd_kernel"):
-        fam = "_fwd_kernel"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*hbm_traffic*{mma}*.json")))
-    if not fam or not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*hbm_traffic*{mma}.json")))
+    if not files:
         return None
     k = json.load(open(files[-1]))["kernels"]
-    sel = [(v["launches"], v["read_MB_per_launch"] + v["write_MB_per_launch"]) for n, v in k.items()
-           if fam in n and "igemm" in n and "<128" in n]
-    n = sum(a for a, _ in sel)
+    if "igemm_pl_fwd" in entry:
+        pick = lambda n: "igemm_pl_fwd_kernel" in n  # noqa: E731
+    elif "igemm_bs_fwd" in entry:
+        pick = lambda n: "igemm_bs_fwd_kernel<128" in n or "igemm_bs_fwd_kernel<256" in n  # noqa: E731
+    else:
+        fam = {"stcat_conv_fwd": "_fwd_kernel", "stcat_conv_dgrad": "_dgrad_kernel", "stcat_conv_wgrad": "_wgrad_kernel",
+               "stcat_pl_conv_wgrad": "igemm_pl_wgrad_kernel"}.get(entry)
+        if not fam:
+            return None
+        pick = lambda n: fam in n and "igemm" in n  # noqa: E731
+    sel = [(v["launches"], v["read_MB_per_launch"], v["write_MB_per_launch"]) for n, v in k.items() if pick(n)]
+    n = sum(a for a, _, _ in sel)
     if not n:
         return None
-    return {"MB_per_launch": round(sum(a * b for a, b in sel) / n, 1), "source": os.path.basename(files[-1]),
-            "note": "128-wide tiles of the family (the conv launches); PMC, separate passes"}
+    return {"MB_per_launch": round(sum(a * (r + w) for a, r, w in sel) / n, 1),
+            "read_MB_per_launch": round(sum(a * r for a, r, _ in sel) / n, 1),
+            "write_MB_per_launch": round(sum(a * w for a, _, w in sel) / n, 1), "source": os.path.basename(files[-1]),
+            "note": "all launches of the kernel family in one step; PMC, separate FETCH_SIZE / WRITE_SIZE passes"}
 
 
 def _pmc_mfma_util():

@@ -22,9 +22,15 @@ for d in sys.argv[1:]:
             launches[k].add(r.get("Dispatch_Id", "0"))
 # one CSV row per counter instance (SE / XCD): SQ counters add up over instances, GRBM_GUI_ACTIVE is the wall clock of
 # the dispatch on every instance -> max (rocprofv3's own MfmaUtil expression: reduce(sum) / reduce(max))
+XCDS = 8
 for (k, _), cs in per_dispatch.items():
     for name, vals in cs.items():
-        agg[k][name] += max(vals) if name.startswith("GRBM") else sum(vals)
+        if name.startswith("GRBM"):
+            # several rows: one per instance -> max.  ONE row: rocprofv3 already summed the 8 XCD instances (the value is
+            # 8x the dispatch's wall cycles: checked against the kernel-trace durations) -> divide
+            agg[k][name] += max(vals) if len(vals) > 1 else vals[0] / XCDS
+        else:
+            agg[k][name] += sum(vals)
 out = {}
 for k, v in agg.items():
     if not any(s in k for s in ("igemm", "mha_", "attn_q1")):
@@ -35,5 +41,6 @@ for k, v in agg.items():
         continue
     out[k] = {"launches": n, "mfma_util_pct": round(100.0 * busy / (act * SIMDS), 2),
               "mfma_busy_cycles_per_launch": round(busy / n), "gpu_active_cycles_per_launch": round(act / n)}
-print(json.dumps({"note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), rocprofv3 --pmc, own pass",
+print(json.dumps({"note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), rocprofv3 --pmc, own pass; "
+                          "GRBM_GUI_ACTIVE arrives summed over the 8 XCDs and is divided by 8",
                   "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"]))}))
