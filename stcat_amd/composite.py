@@ -1,0 +1,263 @@
+"""Composite autograd functions: ONE `torch.autograd.Function` per transformer layer of the grounding model.
+
+Round-1/2 profile (profiles/r02_host_profile.log): the grounding model is ~530 autograd nodes of one or
+two kernels each; `Function.apply` costs ~12 us per node forward and ~45 us through the backward engine, gradient sums
+of multi-consumer tensors run as `at::native` add kernels and packed-parameter slices come back through `cat`.  Here a
+layer's forward is a straight sequence of kernel launches and its backward is written out by hand in reverse order:
+one autograd node per layer, gradient sums fused into the data-gradient epilogues (`add=`) or our own element-wise
+kernel, packed in-projection gradients written straight into their row blocks.  The kernels (and the reference call
+sites they replace) are the ones of `stcat_amd.ops`; only the host-side wiring differs, so every parity test of the
+model covers this path.  `STCAT_NO_COMPOSITE=1` switches back to the op-by-op wiring.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import ops
+
+ENABLED = not os.environ.get("STCAT_NO_COMPOSITE")
+
+
+class _Ctx:
+    """the subset of the autograd ctx API that the Functions of stcat_amd.ops use"""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+def _f(fn, nig, *args):
+    """run fn.forward outside autograd; returns (outputs, ctx)"""
+    c = _Ctx(nig)
+    return fn.forward(c, *args), c
+
+
+_T = (True,) * 8
+
+
+def _add(a, b):
+    return ops.ew(L.EW_ADD, a, b)
+
+
+def _lin_f(x, w, b, res=None, relu=False):
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    r2 = res.reshape(-1, w.shape[0]) if res is not None else None
+    if r2 is not None and not r2.is_contiguous():
+        r2 = r2.contiguous()
+    y = ops.linear_fwd_raw(x2, w, b, r2, relu)
+    return y.view(*shp[:-1], w.shape[0]), x2
+
+
+def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want_db=True):
+    """backward of y = relu?(x2 w^T + b (+ res)): returns (dx [M,K] | None, dw, db, g_after_relu).  `dw` / `db`: zeroed
+    buffers to accumulate into (row blocks of a packed parameter's gradient); `add`: [M,K] tensor summed into dx inside
+    the data-gradient launch."""
+    N, K = w.shape
+    g = g.reshape(-1, N)
+    g = g if g.is_contiguous() else g.contiguous()
+    if relu_y is not None:
+        g, _ = ops.act_bwd_raw(g, relu_y.reshape(-1, N), None, want_g=True, relu=True)
+    M = g.shape[0]
+    st = L.stream_of(g)
+    dx = None
+    if N % 64 == 0:
+        if need_dx:
+            dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+            wt = ops.weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
+            if add is not None:
+                add = add.reshape(M, K)
+                add = add if add.is_contiguous() else add.contiguous()
+            L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), L._ptr(add), L._ptr(wt), dx.data_ptr(), M, N, K, N, K, st)
+        if dw is None:
+            dw = ops._zeros(g, N, K)
+        if db is None and want_db:
+            db = ops._zeros(g, N)
+        L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, K, st)
+    else:
+        dx_ = torch.empty(M, K, device=g.device, dtype=torch.float32) if need_dx else None
+        dw_ = torch.empty(N, K, device=g.device, dtype=torch.float32)
+        db_ = torch.empty(N, device=g.device, dtype=torch.float32) if want_db else None
+        L.call("stcat_small_linear_bwd", g.data_ptr(), x2.data_ptr(), w.data_ptr(), L._ptr(dx_), dw_.data_ptr(),
+               L._ptr(db_), M, N, K, st)
+        dx = dx_ if add is None or dx_ is None else _add(dx_, add.reshape(M, K))
+        dw = dw_ if dw is None else dw.copy_(dw_)
+        db = db_ if db is None else (db.copy_(db_) if db_ is not None else db)
+    return dx, dw, db, g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# shared sub-blocks
+# ------------------------------------------------------------------------------------------------------------------
+def _outln_f(a, Wo, bo, res, g, be, p):
+    """LayerNorm(res + dropout_p(a Wo^T + bo))  (modal_encoder.py:237-238, query_decoder.py:343-345, 431-432, 611-613, 653-654)"""
+    if p > 0.0:
+        h, x_o = _lin_f(a, Wo, bo)
+        y, c_n = _f(ops.LayerNormFn, _T, h, res, g, be, 1e-5, p)
+    else:
+        h, x_o = _lin_f(a, Wo, bo, res=res)          # eval: the residual rides in the GEMM epilogue
+        y, c_n = _f(ops.LayerNormFn, _T, h, None, g, be, 1e-5, 0.0)
+    return y, (c_n, x_o, Wo, p, y.shape)
+
+
+def _outln_b(st, dy, need_da=True):
+    """-> (d_a [M,K], d_res (shape of y), dWo, dbo, dg, dbe)"""
+    c_n, x_o, Wo, p, shp = st
+    r = ops.LayerNormFn.backward(c_n, dy.reshape(shp))
+    d_h, d_res, dg, dbe = r[0], r[1], r[2], r[3]
+    if p == 0.0:
+        d_res = d_h
+    d_a, dWo, dbo, _ = _lin_b(d_h, x_o, Wo, need_dx=need_da)
+    return d_a, d_res, dWo, dbo, dg, dbe
+
+
+def _ffn_f(x, W1, b1, W2, b2, g, be, p):
+    """norm(x + dropout(linear2(dropout(relu(linear1 x)))))  (modal_encoder.py:239-241; query_decoder.py:435-437, 657-659)"""
+    f1, x_1 = _lin_f(x, W1, b1, relu=True)
+    c_dr = None
+    f1d = f1
+    if p > 0.0:
+        f1d, c_dr = _f(ops.DropoutFn, _T, f1, None, p)
+    y, st = _outln_f(f1d, W2, b2, x, g, be, p)
+    return y, (st, c_dr, x_1, f1, W1)
+
+
+def _ffn_b(st, dy):
+    """-> (d_x [M,D], dW1, db1, dW2, db2, dg, dbe)"""
+    st_o, c_dr, x_1, f1, W1 = st
+    d_f1d, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy)
+    d_f1 = ops.DropoutFn.backward(c_dr, d_f1d.view(f1.shape))[0] if c_dr is not None else d_f1d
+    d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, relu_y=f1, add=d_x_res)      # + residual gradient, fused into the dgrad
+    return d_x, dW1, db1, dW2, db2, dg, dbe
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# encoder layer (modal_encoder.py:207-242), post-norm: 12 of them per step
+# ------------------------------------------------------------------------------------------------------------------
+class EncoderLayerFn(Function):
+    @staticmethod
+    def forward(ctx, x, pos, kpm, p, nhead, W_in, B_in, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
+        D = x.shape[-1]
+        shp = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        pos_b = pos if pos.shape == x.shape else pos.expand_as(x)
+        qk_in = ops.ew(L.EW_ADD, x, pos_b if pos_b.is_contiguous() else pos_b.contiguous())      # q = k = src + pos :234
+        qk, x_qk = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
+        v, x_v = _lin_f(x, W_in[2 * D:], B_in[2 * D:])
+        (a, _), c_att = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk, qk[:, :, D:], v, kpm,
+                           (D // nhead) ** -0.5, False, True, p)
+        x1, st1 = _outln_f(a, Wo, bo, x, g1, be1, p)
+        y, st2 = _ffn_f(x1, W1, b1, W2, b2, g2, be2, p)
+        ctx.st = (c_att, st1, st2, x_qk, x_v, D, shp, pos.shape)
+        ctx.W_in = W_in
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (c_att, st1, st2, x_qk, x_v, D, shp, pos_shape) = ctx.st
+        W_in = ctx.W_in
+        need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_x1, dW1, db1, dW2, db2, dg2, dbe2 = _ffn_b(st2, dy)
+        d_a, d_x_res, dWo, dbo, dg1, dbe1 = _outln_b(st1, d_x1)
+        r = ops.MhaSelfFn.backward(c_att, d_a.view(shp), None)
+        dqk, dv = r[0], r[2]
+        dW_in = ops._zeros(dy, 3 * D, D)        # packed in-projection gradient: the two GEMMs write its row blocks
+        dB_in = ops._zeros(dy, 3 * D)
+        d_x, _, _, _ = _lin_b(dv, x_v, W_in[2 * D:], need_dx=need_x, dw=dW_in[2 * D:], db=dB_in[2 * D:],
+                              add=d_x_res if need_x else None)
+        d_pos = None
+        if need_pos:
+            d_qkin, _, _, _ = _lin_b(dqk, x_qk, W_in[:2 * D], dw=dW_in[:2 * D], db=dB_in[:2 * D])
+            if need_x:
+                d_x = _add(d_x, d_qkin)
+            d_pos = d_qkin.view(shp)
+            if tuple(pos_shape) != tuple(shp):
+                d_pos = d_pos.sum_to_size(pos_shape)
+        else:
+            d_x, _, _, _ = _lin_b(dqk, x_qk, W_in[:2 * D], need_dx=need_x, dw=dW_in[:2 * D], db=dB_in[:2 * D],
+                                  add=d_x if need_x else None)
+        return ((d_x.view(shp) if d_x is not None else None), d_pos, None, None, None, dW_in, dB_in, dWo, dbo, dg1, dbe1,
+                dW1, db1, dW2, db2, dg2, dbe2)
+
+
+def encoder_layer(layer, x, pos, kpm, pos_is_const: bool):
+    a = layer.self_attn
+    p = layer.dropout_p if layer.training else 0.0
+    if pos_is_const:
+        pos = pos.detach()
+    return EncoderLayerFn.apply(x, pos, kpm, p, layer.nhead, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight,
+                                a.out_proj.bias, layer.norm1.weight, layer.norm1.bias, layer.linear1.weight,
+                                layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm2.weight,
+                                layer.norm2.bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# time decoder layer (query_decoder.py:553-660)
+# ------------------------------------------------------------------------------------------------------------------
+class TimeDecoderLayerFn(Function):
+    """inputs: tgt [T,D], kc / vv [n,S',D] (this layer's key / value projections of the memory), kpm, query_pos,
+    qpos_time (= query_pos + time embedding) -> (out [T,D], head-mean self-attention weights [1,T,T])"""
+
+    @staticmethod
+    def forward(ctx, tgt, kc, vv, kpm, query_pos, qpos_time, p, nhead, W_in, B_in, Wo, bo, g1, be1, Wcq, Bcq, Wo2, bo2,
+                g3, be3, W1, b1, W2, b2, g4, be4):
+        T, D = tgt.shape
+        hd = D // nhead
+        tgt = tgt if tgt.is_contiguous() else tgt.contiguous()
+        qk_in = ops.ew(L.EW_ADD, tgt, qpos_time.contiguous())                                # :602
+        qk, x_qk = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
+        v, x_v = _lin_f(tgt, W_in[2 * D:], B_in[2 * D:])
+        (a, w), c_att = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk[None], qk[None][:, :, D:], v[None], None,
+                           hd ** -0.5, True, True, p)                                        # :604-610
+        tgt1, st1 = _outln_f(a[0], Wo, bo, tgt, g1, be1, p)
+        qc_in = ops.ew(L.EW_ADD, tgt1, query_pos.contiguous())                               # :633-634
+        qc, x_qc = _lin_f(qc_in, Wcq, Bcq)
+        a2, c_q1 = _f(ops.AttnQ1Fn, _T, qc, None, kc, None, vv, kpm, hd ** -0.5, p)
+        tgt2, st3 = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)                                 # :653-654
+        out, st4 = _ffn_f(tgt2, W1, b1, W2, b2, g4, be4, p)                                  # :657-659
+        ctx.st = (c_att, st1, c_q1, st3, st4, x_qk, x_v, x_qc, T, D)
+        ctx.Ws = (W_in, Wcq)
+        return out, w
+
+    @staticmethod
+    def backward(ctx, d_out, d_w):
+        (c_att, st1, c_q1, st3, st4, x_qk, x_v, x_qc, T, D) = ctx.st
+        W_in, Wcq = ctx.Ws
+        d_tgt2, dW1, db1, dW2, db2, dg4, dbe4 = _ffn_b(st4, d_out)
+        d_a2, d_tgt1_res, dWo2, dbo2, dg3, dbe3 = _outln_b(st3, d_tgt2)
+        r = ops.AttnQ1Fn.backward(c_q1, d_a2)
+        dqc, dkc, dvv = r[0], r[2], r[4]
+        d_qcin, dWcq, dBcq, _ = _lin_b(dqc, x_qc, Wcq)           # gradient of (tgt1 + query_pos)
+        d_tgt1 = _add(d_tgt1_res.reshape(T, D), d_qcin)
+        d_a, d_tgt_res, dWo, dbo, dg1, dbe1 = _outln_b(st1, d_tgt1)
+        r = ops.MhaSelfFn.backward(c_att, d_a.view(1, T, D), d_w)
+        dqk, dv = r[0], r[2]
+        dW_in = ops._zeros(d_out, 3 * D, D)
+        dB_in = ops._zeros(d_out, 3 * D)
+        d_t, _, _, _ = _lin_b(dv[0], x_v, W_in[2 * D:], dw=dW_in[2 * D:], db=dB_in[2 * D:], add=d_tgt_res.reshape(T, D))
+        d_qkin, _, _, _ = _lin_b(dqk[0], x_qk, W_in[:2 * D], dw=dW_in[:2 * D], db=dB_in[:2 * D])
+        d_tgt = _add(d_t, d_qkin)
+        return (d_tgt, dkc, dvv, None, d_qcin, d_qkin, None, None, dW_in, dB_in, dWo, dbo, dg1, dbe1, dWcq, dBcq, dWo2,
+                dbo2, dg3, dbe3, dW1, db1, dW2, db2, dg4, dbe4)
+
+
+def time_decoder_layer(layer, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
+    p = layer.dropout_p if layer.training else 0.0
+    sa, ca = layer.self_attn, layer.cross_attn_image
+    return TimeDecoderLayerFn.apply(tgt, kc, vv, kpm, query_pos, qpos_time, p, layer.nhead, sa.in_proj_weight,
+                                    sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.norm1.weight,
+                                    layer.norm1.bias, Wcq, Bcq, ca.out_proj.weight, ca.out_proj.bias, layer.norm3.weight,
+                                    layer.norm3.bias, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight,
+                                    layer.linear2.bias, layer.norm4.weight, layer.norm4.bias)

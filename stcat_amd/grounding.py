@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import composite, ops
 from .misc import NestedTensor
 
 D_MODEL = 256
@@ -108,6 +108,8 @@ class TransformerEncoderLayer(nn.Module):
 
     def run(self, x, pos, kpm, pos_is_const: bool):
         """x, pos: [B,S,256] batch-first; kpm [B,S] bool or None."""
+        if composite.ENABLED:  # one autograd node per layer, hand-written backward (stcat_amd/composite.py)
+            return composite.encoder_layer(self, x, pos, kpm, pos_is_const)
         D = x.shape[-1]
         p = self.dropout_p if self.training else 0.0
         (Wqk, Wv), (Bqk, Bv) = (ops.split_rows(self.self_attn.in_proj_weight, (2 * D, D)),
@@ -347,6 +349,8 @@ class TimeDecoderLayer(nn.Module):
     def run(self, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
         """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory; Wcq/Bcq: the query
         rows of cross_attn_image's packed in-projection (split once in TimeDecoder.run)."""
+        if composite.ENABLED:
+            return composite.time_decoder_layer(self, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq)
         T, D = tgt.shape
         hd = D // self.nhead
         p = self.dropout_p if self.training else 0.0
