@@ -177,6 +177,11 @@ int stcat_layernorm_bwd(const float* dy, const float* x, const float* res, const
 /* element-wise glue; op codes STCAT_EW_* below; b indexed modulo bmod */
 int stcat_ew(int op, const float* a, const float* b, const float* c, float* out, long n, long bmod, float alpha,
              float beta, void* stream);
+/* row-strided two-operand form (ADD, MUL, AXPBY, COPY): out[r*ldo + c] = op(a[r*lda + c], b[r*ldb + c]); column blocks of
+ * wider matrices (a decoder layer's slice of the layer-batched key/value projections, query_decoder.py:355-358; the
+ * first half of the anchor sine embedding, query_decoder.py:193-200) without a gather copy */
+int stcat_ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int cols,
+               float alpha, float beta, void* stream);
 enum {
   STCAT_EW_ADD = 0, STCAT_EW_MUL = 1, STCAT_EW_SIGMOID = 2, STCAT_EW_TANH = 3, STCAT_EW_RELU = 4,
   STCAT_EW_INVSIG = 5, STCAT_EW_SIGMOID_BWD = 6, STCAT_EW_TANH_BWD = 7, STCAT_EW_INVSIG_BWD = 8,

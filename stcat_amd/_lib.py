@@ -42,6 +42,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_layernorm_fwd": "pppppppiif" + "fllps",
     "stcat_layernorm_bwd": "ppppppppppii" + "fllps",
     "stcat_ew": "ipppp" + "llffs",
+    "stcat_ew2d": "iplplpllif" + "fs",
     "stcat_dropout": "ppplfllps",
     "stcat_mha_self_fwd": "ppppppiiiiiiif" + "fllps",
     "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "fllps",

@@ -52,8 +52,9 @@ def _add(a, b):
 
 def _lin_f(x, w, b, res=None, relu=False):
     shp = x.shape
-    x2 = x.reshape(-1, shp[-1])
-    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    x2 = x if x.dim() == 2 else x.reshape(-1, shp[-1])
+    if not (x2.is_contiguous() or (x2.stride(1) == 1 and w.shape[0] % 64 == 0)):      # row-strided is fine for the GEMM
+        x2 = x2.contiguous()
     r2 = res.reshape(-1, w.shape[0]) if res is not None else None
     if r2 is not None and not r2.is_contiguous():
         r2 = r2.contiguous()
@@ -85,7 +86,7 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
             dw = ops._zeros(g, N, K)
         if db is None and want_db:
             db = ops._zeros(g, N)
-        L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, K, st)
+        L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, x2.stride(0), st)
     else:
         dx_ = torch.empty(M, K, device=g.device, dtype=torch.float32) if need_dx else None
         dw_ = torch.empty(N, K, device=g.device, dtype=torch.float32)
@@ -93,8 +94,8 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
         L.call("stcat_small_linear_bwd", g.data_ptr(), x2.data_ptr(), w.data_ptr(), L._ptr(dx_), dw_.data_ptr(),
                L._ptr(db_), M, N, K, st)
         dx = dx_ if add is None or dx_ is None else _add(dx_, add.reshape(M, K))
-        dw = dw_ if dw is None else dw.copy_(dw_)
-        db = db_ if db is None else (db.copy_(db_) if db_ is not None else db)
+        dw = dw_ if dw is None else ops.ew(L.EW_ADD, dw, dw_, out=dw)
+        db = db_ if db is None else (ops.ew(L.EW_ADD, db, db_, out=db) if db_ is not None else db)
     return dx, dw, db, g
 
 
@@ -261,3 +262,227 @@ def time_decoder_layer(layer, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
                                     layer.norm1.bias, Wcq, Bcq, ca.out_proj.weight, ca.out_proj.bias, layer.norm3.weight,
                                     layer.norm3.bias, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight,
                                     layer.linear2.bias, layer.norm4.weight, layer.norm4.bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# box decoder: all layers + the anchor-update loop around them (query_decoder.py:150-247, 250-438) as ONE node
+# ------------------------------------------------------------------------------------------------------------------
+_N_SHARED = 16      # ref_point_head (W,b)x2, query_scale (W,b)x2, bbox_embed (W,b)x3, norm (g,b)
+_N_LAYER = 36
+
+
+def _ln_f(x, g, be, out=None):
+    M, D = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    mean = ops._empty(x, M)
+    rstd = ops._empty(x, M)
+    L.call("stcat_layernorm_fwd", x.data_ptr(), None, g.data_ptr(), be.data_ptr(), y.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), M, D, 1e-5, 0.0, 0, 0, None, L.stream_of(x))
+    return y, (x, g, mean, rstd)
+
+
+def _ln_b(st, dy, dg, dbe):
+    """dz; dg / dbe accumulate (the kernel adds into caller-zeroed buffers)"""
+    x, g, mean, rstd = st
+    M, D = x.shape
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    dz = torch.empty_like(x)
+    L.call("stcat_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+           dz.data_ptr(), None, dg.data_ptr(), dbe.data_ptr(), M, D, 0.0, 0, 0, None, L.stream_of(x))
+    return dz
+
+
+class BoxDecoderFn(Function):
+    """inputs: kc / kp / vv [n,S',L*D] = ca_kcontent_proj(memory), ca_kpos_proj(pos), ca_v_proj(memory) of all layers
+    (TransformerDecoder.memory_projections), kpm, anchor [T,4], time_embed [T,D] -> (hs [L,T,D], refs [L,T,4]).
+    Shared modules (ref_point_head, query_scale, bbox_embed, norm) accumulate their gradients over the layers inside
+    the node instead of through L AccumulateGrad adds."""
+
+    @staticmethod
+    def forward(ctx, kc, kp, vv, kpm, anchor, time_embed, p, nhead, nl, *prm):
+        T = anchor.shape[0]
+        D = time_embed.shape[1]
+        hd = D // nhead
+        sh = prm[:_N_SHARED]
+        (Wr1, br1, Wr2, br2, Ws1, bs1, Ws2, bs2, Wb1, bb1, Wb2, bb2, Wb3, bb3, gN, beN) = sh
+        anchor = anchor.contiguous()
+        time_embed = time_embed.contiguous()
+        hs = ops._empty(anchor, nl, T, D)
+        refs = ops._empty(anchor, nl, T, 4)
+        ops.ew(L.EW_COPY, anchor, out=refs[0])
+        out = ops._zeros(anchor, T, D)
+        states = []
+        for i in range(nl):
+            lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]
+            (Wqc, bqc, Wqp, bqp, Wqt, bqt, Wkc, bkc, Wkp, bkp, Wkt, bkt, Wv, bv, W_in, B_in, Wo, bo, g1, be1, Wcq, bcq,
+             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = lp
+            first = i == 0
+            st = {}
+            sine, st["sine"] = _f(ops.SineEmbedFn, _T, anchor)                                # [T,512]  :190
+            h_r, st["x_r1"] = _lin_f(sine, Wr1, br1, relu=True)                               # ref_point_head :191
+            qpos, st["x_r2"] = _lin_f(h_r, Wr2, br2)
+            st["h_r"] = h_r
+            sine_h = sine[:, :D]
+            if first:
+                sine_q = sine_h                                                              # row-strided view
+            else:                                                                            # :194-200
+                h_s, st["x_s1"] = _lin_f(out, Ws1, bs1, relu=True)
+                qsc, st["x_s2"] = _lin_f(h_s, Ws2, bs2)
+                st["h_s"] = h_s
+                sine_q = ops.ew2d(L.EW_MUL, sine_h, qsc)
+            st["sine_h"] = sine_h
+            # ---- the layer: self-attention over the T queries :329-345
+            t, _ = _lin_f(out, Wqc, bqc)
+            t, _ = _lin_f(time_embed, Wqt, bqt, res=t)
+            q, _ = _lin_f(qpos, Wqp, bqp, res=t)
+            t, _ = _lin_f(out, Wkc, bkc)
+            t, _ = _lin_f(time_embed, Wkt, bkt, res=t)
+            k, _ = _lin_f(qpos, Wkp, bkp, res=t)
+            v, _ = _lin_f(out, Wv, bv)
+            qp, _ = _lin_f(q, W_in[:D], B_in[:D])
+            kp_, _ = _lin_f(k, W_in[D:2 * D], B_in[D:2 * D])
+            vp, _ = _lin_f(v, W_in[2 * D:], B_in[2 * D:])
+            (a, _), st["att"] = _f(ops.MhaSelfFn, _T, qp[None], kp_[None], vp[None], None, hd ** -0.5, False, False, p)
+            tgt1, st["o1"] = _outln_f(a[0], Wo, bo, out, g1, be1, p)
+            st["sa_in"] = (out, qpos, q, k, v)
+            # ---- time-aligned cross-attention :355-432
+            qc, _ = _lin_f(tgt1, Wcq, bcq)
+            kci, kpi, vvi = kc[..., i * D:(i + 1) * D], kp[..., i * D:(i + 1) * D], vv[..., i * D:(i + 1) * D]
+            if first:                                                                        # :360-366
+                qc, _ = _lin_f(qpos, Wcqp, bcqp, res=qc)
+                kpi = ops.ew2d(L.EW_COPY, kpi)          # k1 and k2 must share one leading dimension in the kernel
+                kci = ops.ew2d(L.EW_ADD, kci, kpi)
+            qs, st["x_qs"] = _lin_f(sine_q, Wqs, bqs)                                        # :369
+            a2, st["q1"] = _f(ops.AttnQ1Fn, _T, qc, qs, kci, kpi, vvi, kpm, (2 * hd) ** -0.5, p)
+            tgt2, st["o3"] = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)
+            st["tgt1"] = tgt1
+            out, st["ffn"] = _ffn_f(tgt2, W1, b1, W2, b2, g4, be4, p)                          # :435-437
+            # ---- anchor update :212-219 (the last layer's update is never read: not computed)
+            if i != nl - 1:
+                e1, st["x_b1"] = _lin_f(out, Wb1, bb1, relu=True)
+                e2, st["x_b2"] = _lin_f(e1, Wb2, bb2, relu=True)
+                tmp, st["x_b3"] = _lin_f(e2, Wb3, bb3)
+                st["e"] = (e1, e2)
+                pre = ops.ew(L.EW_ADD, tmp, ops.ew(L.EW_INVSIG, anchor))
+                ops.ew(L.EW_SIGMOID, pre, out=refs[i + 1])
+                st["anchor"] = anchor
+                anchor = refs[i + 1]
+            _, st["norm"] = _ln_f(out, gN, beN, out=hs[i])                                   # :221-229
+            states.append(st)
+        ctx.states = states
+        ctx.prm = prm
+        ctx.time_embed = time_embed
+        ctx.dims = (T, D, nl, kc.shape)
+        ctx.refs = refs
+        return hs, ops.ew(L.EW_COPY, refs)       # (a copy: the node keeps `refs`, and an output held by its own node is a cycle)
+
+    @staticmethod
+    def backward(ctx, d_hs, d_refs):
+        T, D, nl, kshape = ctx.dims
+        prm, refs = ctx.prm, ctx.refs
+        need_anchor = ctx.needs_input_grad[4]
+        (Wr1, br1, Wr2, br2, Ws1, bs1, Ws2, bs2, Wb1, bb1, Wb2, bb2, Wb3, bb3, gN, beN) = prm[:_N_SHARED]
+        like = d_hs
+        z = lambda t: ops._zeros(like, *t.shape)      # noqa: E731
+        d_sh = [z(t) for t in prm[:_N_SHARED]]       # shared-module gradients: accumulated across the layers
+        (dWr1, dbr1, dWr2, dbr2, dWs1, dbs1, dWs2, dbs2, dWb1, dbb1, dWb2, dbb2, dWb3, dbb3, dgN, dbeN) = d_sh
+        d_hs = d_hs if d_hs.is_contiguous() else d_hs.contiguous()
+        if d_refs is not None and not d_refs.is_contiguous():
+            d_refs = d_refs.contiguous()
+        d_kc = ops._empty(like, *kshape)
+        d_kp = ops._empty(like, *kshape)
+        d_vv = ops._empty(like, *kshape)
+        d_layers = [None] * nl
+        d_anchor = None
+        d_next = None                                  # gradient reaching layer i's output state from layer i+1
+        for i in reversed(range(nl)):
+            st = ctx.states[i]
+            lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]
+            (Wqc, bqc, Wqp, bqp, Wqt, bqt, Wkc, bkc, Wkp, bkp, Wkt, bkt, Wv, bv, W_in, B_in, Wo, bo, g1, be1, Wcq, bcq,
+             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = lp
+            first = i == 0
+            d_out = _ln_b(st["norm"], d_hs[i], dgN, dbeN)
+            if d_next is not None:
+                d_out = _add(d_out, d_next)
+            if i != nl - 1 and d_refs is not None:
+                d_pre = ops.ew(L.EW_SIGMOID_BWD, d_refs[i + 1], refs[i + 1])
+                if first and need_anchor:
+                    d_anchor = ops.ew(L.EW_INVSIG_BWD, d_pre, st["anchor"])
+                e1, e2 = st["e"]
+                d_e2, _, _, _ = _lin_b(d_pre, st["x_b3"], Wb3, dw=dWb3, db=dbb3)
+                d_e1, _, _, _ = _lin_b(d_e2, st["x_b2"], Wb2, dw=dWb2, db=dbb2, relu_y=e2)
+                d_out, _, _, _ = _lin_b(d_e1, st["x_b1"], Wb1, dw=dWb1, db=dbb1, relu_y=e1, add=d_out)
+            # ---- layer backward
+            x_out, qpos, q, k, v = st["sa_in"]
+            d_tgt2, dW1, db1, dW2, db2, dg4, dbe4 = _ffn_b(st["ffn"], d_out)
+            d_a2, d_tgt1_res, dWo2, dbo2, dg3, dbe3 = _outln_b(st["o3"], d_tgt2)
+            r = ops.AttnQ1Fn.backward(st["q1"], d_a2)
+            dqc, dqs, dk1, dk2, dvv_i = r[0], r[1], r[2], r[3], r[4]
+            cs = slice(i * D, (i + 1) * D)
+            ops.ew2d(L.EW_COPY, dk1, out=d_kc[..., cs])
+            if first:
+                ops.ew2d(L.EW_ADD, dk1, dk2, out=d_kp[..., cs])
+            else:
+                ops.ew2d(L.EW_COPY, dk2, out=d_kp[..., cs])
+            ops.ew2d(L.EW_COPY, dvv_i, out=d_vv[..., cs])
+            d_sine_q, dWqs, dbqs, _ = _lin_b(dqs, st["x_qs"], Wqs, need_dx=(not first) or need_anchor)
+            d_qpos = None
+            dWcqp = dbcqp = None
+            if first:
+                d_qpos, dWcqp, dbcqp, _ = _lin_b(dqc, qpos, Wcqp)
+            d_tgt1, dWcq, dbcq, _ = _lin_b(dqc, st["tgt1"], Wcq, add=d_tgt1_res)
+            d_a, d_out_res, dWo, dbo, dg1, dbe1 = _outln_b(st["o1"], d_tgt1)
+            r = ops.MhaSelfFn.backward(st["att"], d_a.view(1, T, D), None)
+            dW_in = ops._zeros(like, 3 * D, D)
+            dB_in = ops._zeros(like, 3 * D)
+            d_q, _, _, _ = _lin_b(r[0][0], q, W_in[:D], dw=dW_in[:D], db=dB_in[:D])
+            d_k, _, _, _ = _lin_b(r[1][0], k, W_in[D:2 * D], dw=dW_in[D:2 * D], db=dB_in[D:2 * D])
+            d_v, _, _, _ = _lin_b(r[2][0], v, W_in[2 * D:], dw=dW_in[2 * D:], db=dB_in[2 * D:])
+            nd = not first                              # layer 0's input state is the constant zero tensor
+            d_qpos, dWqp, dbqp, _ = _lin_b(d_q, qpos, Wqp, add=d_qpos)
+            _, dWqt, dbqt, _ = _lin_b(d_q, ctx.time_embed, Wqt, need_dx=False)
+            d_x, dWqc, dbqc, _ = _lin_b(d_q, x_out, Wqc, need_dx=nd, add=d_out_res.reshape(T, D) if nd else None)
+            d_qpos, dWkp, dbkp, _ = _lin_b(d_k, qpos, Wkp, add=d_qpos)
+            _, dWkt, dbkt, _ = _lin_b(d_k, ctx.time_embed, Wkt, need_dx=False)
+            d_x, dWkc, dbkc, _ = _lin_b(d_k, x_out, Wkc, need_dx=nd, add=d_x)
+            d_x, dWv, dbv, _ = _lin_b(d_v, x_out, Wv, need_dx=nd, add=d_x)
+            # ---- query_scale / ref_point_head / sine embedding
+            if not first:
+                d_qsc = ops.ew2d(L.EW_MUL, d_sine_q, st["sine_h"])
+                d_hs_, _, _, _ = _lin_b(d_qsc, st["x_s2"], Ws2, dw=dWs2, db=dbs2)
+                d_x, _, _, _ = _lin_b(d_hs_, st["x_s1"], Ws1, dw=dWs1, db=dbs1, relu_y=st["h_s"], add=d_x)
+            d_hr, _, _, _ = _lin_b(d_qpos, st["x_r2"], Wr2, dw=dWr2, db=dbr2)
+            d_sine, _, _, _ = _lin_b(d_hr, st["x_r1"], Wr1, dw=dWr1, db=dbr1, relu_y=st["h_r"],
+                                     need_dx=first and need_anchor)
+            if first and need_anchor:
+                ops.ew2d(L.EW_ADD, d_sine[:, :D], d_sine_q, out=d_sine[:, :D])
+                d_a0 = ops.SineEmbedFn.backward(st["sine"], d_sine)
+                d_anchor = _add(d_anchor, d_a0) if d_anchor is not None else d_a0
+                if d_refs is not None:
+                    d_anchor = _add(d_anchor, d_refs[0])
+            d_next = d_x
+            d_layers[i] = (dWqc, dbqc, dWqp, dbqp, dWqt, dbqt, dWkc, dbkc, dWkp, dbkp, dWkt, dbkt, dWv, dbv, dW_in, dB_in,
+                           dWo, dbo, dg1, dbe1, dWcq, dbcq, dWcqp, dbcqp, dWqs, dbqs, dWo2, dbo2, dg3, dbe3, dW1, db1,
+                           dW2, db2, dg4, dbe4)
+        flat = tuple(d_sh)
+        for t in d_layers:
+            flat += t
+        return (d_kc, d_kp, d_vv, None, d_anchor, None, None, None, None) + flat
+
+
+def box_decoder(dec, kc, kp, vv, kpm, anchor, time_embed):
+    """dec: grounding.TransformerDecoder; kc/kp/vv: the layer-batched memory projections [n,S',L*D]"""
+    p = dec.layers[0].dropout_p if dec.training else 0.0
+    wb = lambda m: (m.weight, m.bias)       # noqa: E731
+    prm = (wb(dec.ref_point_head.layers[0]) + wb(dec.ref_point_head.layers[1]) + wb(dec.query_scale.layers[0])
+           + wb(dec.query_scale.layers[1]) + wb(dec.bbox_embed.layers[0]) + wb(dec.bbox_embed.layers[1])
+           + wb(dec.bbox_embed.layers[2]) + wb(dec.norm))
+    for l in dec.layers:
+        sa = l.self_attn
+        prm += (wb(l.sa_qcontent_proj) + wb(l.sa_qpos_proj) + wb(l.sa_qtime_proj) + wb(l.sa_kcontent_proj)
+                + wb(l.sa_kpos_proj) + wb(l.sa_ktime_proj) + wb(l.sa_v_proj)
+                + (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias) + wb(l.norm1)
+                + wb(l.ca_qcontent_proj) + (wb(l.ca_qpos_proj) if l.ca_qpos_proj is not None else (None, None))
+                + wb(l.ca_qpos_sine_proj) + wb(l.cross_attn.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2)
+                + wb(l.norm4))
+    return BoxDecoderFn.apply(kc, kp, vv, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)

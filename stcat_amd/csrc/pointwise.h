@@ -177,6 +177,26 @@ __global__ void __launch_bounds__(256) ew_kernel(int op, const float* a, const f
   }
 }
 
+// row-strided form of the two-operand ops (column blocks of wider matrices: a layer's slice of a layer-batched projection,
+// the first half of the anchor sine embedding): out[r][c] = op(a[r][c], b[r][c]) with independent leading dimensions.
+__global__ void __launch_bounds__(256) ew2d_kernel(int op, const float* a, long lda, const float* b, long ldb, float* out,
+                                                  long ldo, long rows, int cols, float alpha, float beta) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float x = a[r * lda + c];
+    float v;
+    switch (op) {
+      case EW_ADD: v = x + b[r * ldb + c]; break;
+      case EW_MUL: v = x * b[r * ldb + c]; break;
+      case EW_AXPBY: v = alpha * x + beta * b[r * ldb + c]; break;
+      default: v = x; break;   // EW_COPY
+    }
+    out[r * ldo + c] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // anchor sine embedding (net_utils.py:29-56): anchors [M][4] (x,y,w,h) -> [M][512] (y,x,w,h blocks)
 // dimt: 128 divisors 10000^(2*floor(i/2)/128), precomputed in fp32 by the host.

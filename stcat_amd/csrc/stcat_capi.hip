@@ -671,6 +671,17 @@ int stcat_ew(int op, const float* a, const float* b, const float* c, float* out,
   return launch_status();
 }
 
+int stcat_ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int cols,
+               float alpha, float beta, void* stream) {
+  if (rows <= 0 || cols <= 0) return fail("ew2d: rows=%ld cols=%d", rows, cols);
+  if (op != EW_ADD && op != EW_MUL && op != EW_AXPBY && op != EW_COPY) return fail("ew2d: op %d is not a two-operand op / copy", op);
+  if (op != EW_COPY && !b) return fail("ew2d: op %d needs b", op);
+  if (lda < cols || ldo < cols || (b && ldb < cols)) return fail("ew2d: leading dimension below cols");
+  STCAT_LAUNCH(ew2d_kernel, dim3(grid_for(rows * cols, 256, 4096)), dim3(256), 0, (hipStream_t)stream, op, a, lda, b, ldb,
+               out, ldo, rows, cols, alpha, beta);
+  return launch_status();
+}
+
 int stcat_dropout(const float* x, const float* res, float* y, long n, float p, long seed, long offset,
                   const long* base, void* stream) {
   if (n <= 0) return fail("dropout: n=%ld", n);

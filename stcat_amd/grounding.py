@@ -299,19 +299,23 @@ class TransformerDecoder(nn.Module):
         for layer_id in range(num_layers - 1):
             self.layers[layer_id + 1].ca_qpos_proj = None                                    # :166-167
 
-    def memory_projections(self, memory, pos):
+    def memory_projections(self, memory, pos, split=True):
         """ca_kcontent_proj / ca_v_proj of `memory` and ca_kpos_proj of `pos` for ALL layers as three GEMMs
         with N = layers*256 (query_decoder.py:355-358 computes them layer by layer on the same inputs)."""
         L_ = self.num_layers
         cat = lambda nm, leaf: torch.cat([getattr(getattr(l, nm), leaf) for l in self.layers], dim=0)  # noqa: E731
-        kc = ops.split_cols(ops.linear(memory, cat("ca_kcontent_proj", "weight"), cat("ca_kcontent_proj", "bias")), L_)
-        vv = ops.split_cols(ops.linear(memory, cat("ca_v_proj", "weight"), cat("ca_v_proj", "bias")), L_)
-        kp = ops.split_cols(ops.linear(pos, cat("ca_kpos_proj", "weight"), cat("ca_kpos_proj", "bias")), L_)
-        return kc, kp, vv
+        kc = ops.linear(memory, cat("ca_kcontent_proj", "weight"), cat("ca_kcontent_proj", "bias"))
+        vv = ops.linear(memory, cat("ca_v_proj", "weight"), cat("ca_v_proj", "bias"))
+        kp = ops.linear(pos, cat("ca_kpos_proj", "weight"), cat("ca_kpos_proj", "bias"))
+        if not split:
+            return kc, kp, vv
+        return ops.split_cols(kc, L_), ops.split_cols(kp, L_), ops.split_cols(vv, L_)
 
     def run(self, memory, kpm, pos, anchor, time_embed):
         """memory/pos [n,S',256]; anchor [T,4] (sigmoid-ed template); returns hs [L,T,256], refs [L,T,4]."""
         T = anchor.shape[0]
+        if composite.ENABLED:
+            return composite.box_decoder(self, *self.memory_projections(memory, pos, split=False), kpm, anchor, time_embed)
         kc, kp, vv = self.memory_projections(memory, pos)
         out = torch.zeros(T, self.d_model, device=memory.device)
         inter, refs = [], [anchor]

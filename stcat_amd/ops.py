@@ -156,6 +156,31 @@ def ew(op: int, a, b=None, c=None, bmod: int = 0, alpha: float = 1.0, beta: floa
     return out
 
 
+def ew2d(op: int, a, b=None, out=None, alpha: float = 1.0, beta: float = 1.0):
+    """two-operand op / copy on [..., C] operands whose rows may be strided (column blocks of wider matrices)"""
+    C = a.shape[-1]
+
+    def rows(t):
+        if t.dim() == 2:
+            t2 = t
+        elif t.is_contiguous():
+            t2 = t.view(-1, C)
+        else:
+            t2 = t.reshape(-1, C) if t.stride(-1) == 1 and all(
+                t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2)) else _c(t).view(-1, C)
+        assert t2.stride(1) == 1
+        return t2
+    a2 = rows(a)
+    b2 = rows(b) if b is not None else None
+    ret = out if out is not None else torch.empty(a.shape, device=a.device, dtype=a.dtype)
+    o2 = rows(ret)
+    assert o2.data_ptr() == ret.data_ptr()
+    _chk(a2, b2)
+    L.call("stcat_ew2d", op, a2.data_ptr(), a2.stride(0), L._ptr(b2), (b2.stride(0) if b2 is not None else 0), o2.data_ptr(),
+           o2.stride(0), a2.shape[0], C, alpha, beta, L.stream_of(a2))
+    return ret
+
+
 def colsum(a2d: torch.Tensor, b2d: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, N = a2d.shape
     out = _zeros(a2d, N)
