@@ -144,6 +144,27 @@ def _ffn_b(st, dy):
     return d_x, dW1, db1, dW2, db2, dg, dbe
 
 
+def _ln_f(x, g, be, out=None):
+    M, D = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    mean = ops._empty(x, M)
+    rstd = ops._empty(x, M)
+    L.call("stcat_layernorm_fwd", x.data_ptr(), None, g.data_ptr(), be.data_ptr(), y.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), M, D, 1e-5, 0.0, 0, 0, None, L.stream_of(x))
+    return y, (x, g, mean, rstd)
+
+
+def _ln_b(st, dy, dg, dbe):
+    """dz; dg / dbe accumulate (the kernel adds into caller-zeroed buffers)"""
+    x, g, mean, rstd = st
+    M, D = x.shape
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    dz = torch.empty_like(x)
+    L.call("stcat_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+           dz.data_ptr(), None, dg.data_ptr(), dbe.data_ptr(), M, D, 0.0, 0, 0, None, L.stream_of(x))
+    return dz
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # encoder layer (modal_encoder.py:207-242), post-norm: 12 of them per step
 # ------------------------------------------------------------------------------------------------------------------
@@ -205,102 +226,139 @@ def encoder_layer(layer, x, pos, kpm, pos_is_const: bool):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# time decoder layer (query_decoder.py:553-660)
+# time decoder: all layers (query_decoder.py:478-550, 553-660) as ONE node
 # ------------------------------------------------------------------------------------------------------------------
-class TimeDecoderLayerFn(Function):
-    """inputs: tgt [T,D], kc / vv [n,S',D] (this layer's key / value projections of the memory), kpm, query_pos,
-    qpos_time (= query_pos + time embedding) -> (out [T,D], head-mean self-attention weights [1,T,T])"""
+_NT_LAYER = 18
+
+
+class TimeDecoderFn(Function):
+    """inputs: memory [n,S',D], pos [n,S',D] (constant), kpm, query_pos [T,D], time_pos [T,D] (constant) ->
+    (hs [L,T,D], head-mean self-attention weights [L,1,T,T]).  Each layer projects (memory + pos) / memory with the
+    key / value rows of its packed cross_attn_image in-projection (:633-639); the packed gradients are written in place."""
 
     @staticmethod
-    def forward(ctx, tgt, kc, vv, kpm, query_pos, qpos_time, p, nhead, W_in, B_in, Wo, bo, g1, be1, Wcq, Bcq, Wo2, bo2,
-                g3, be3, W1, b1, W2, b2, g4, be4):
-        T, D = tgt.shape
+    def forward(ctx, memory, pos, kpm, query_pos, time_pos, p, nhead, nl, gN, beN, *prm):
+        T, D = query_pos.shape
         hd = D // nhead
-        tgt = tgt if tgt.is_contiguous() else tgt.contiguous()
-        qk_in = ops.ew(L.EW_ADD, tgt, qpos_time.contiguous())                                # :602
-        qk, x_qk = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
-        v, x_v = _lin_f(tgt, W_in[2 * D:], B_in[2 * D:])
-        (a, w), c_att = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk[None], qk[None][:, :, D:], v[None], None,
-                           hd ** -0.5, True, True, p)                                        # :604-610
-        tgt1, st1 = _outln_f(a[0], Wo, bo, tgt, g1, be1, p)
-        qc_in = ops.ew(L.EW_ADD, tgt1, query_pos.contiguous())                               # :633-634
-        qc, x_qc = _lin_f(qc_in, Wcq, Bcq)
-        a2, c_q1 = _f(ops.AttnQ1Fn, _T, qc, None, kc, None, vv, kpm, hd ** -0.5, p)
-        tgt2, st3 = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)                                 # :653-654
-        out, st4 = _ffn_f(tgt2, W1, b1, W2, b2, g4, be4, p)                                  # :657-659
-        ctx.st = (c_att, st1, c_q1, st3, st4, x_qk, x_v, x_qc, T, D)
-        ctx.Ws = (W_in, Wcq)
-        return out, w
+        memory = memory if memory.is_contiguous() else memory.contiguous()
+        query_pos = query_pos if query_pos.is_contiguous() else query_pos.contiguous()
+        mem_pos = ops.ew(L.EW_ADD, memory, pos)                                               # :636
+        qpos_time = ops.ew(L.EW_ADD, query_pos, time_pos)                                     # :602
+        hs = ops._empty(memory, nl, T, D)
+        ws = ops._empty(memory, nl, 1, T, T)
+        out = ops._zeros(memory, T, D)
+        states = []
+        x_mp = x_mem = None
+        for i in range(nl):
+            (W_in, B_in, Wo, bo, g1, be1, W_c, B_c, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = \
+                prm[i * _NT_LAYER:(i + 1) * _NT_LAYER]
+            st = {}
+            qk_in = ops.ew(L.EW_ADD, out, qpos_time)
+            qk, st["x_qk"] = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
+            v, st["x_v"] = _lin_f(out, W_in[2 * D:], B_in[2 * D:])
+            (a, w), st["att"] = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk[None], qk[None][:, :, D:], v[None],
+                                   None, hd ** -0.5, True, True, p)                          # :604-610
+            ops.ew(L.EW_COPY, w, out=ws[i])
+            tgt1, st["o1"] = _outln_f(a[0], Wo, bo, out, g1, be1, p)
+            qc_in = ops.ew(L.EW_ADD, tgt1, query_pos)                                         # :633-634
+            qc, st["x_qc"] = _lin_f(qc_in, W_c[:D], B_c[:D])
+            kci, x_mp = _lin_f(mem_pos, W_c[D:2 * D], B_c[D:2 * D])
+            vvi, x_mem = _lin_f(memory, W_c[2 * D:], B_c[2 * D:])
+            a2, st["q1"] = _f(ops.AttnQ1Fn, _T, qc, None, kci, None, vvi, kpm, hd ** -0.5, p)
+            tgt2, st["o3"] = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)                         # :653-654
+            out, st["ffn"] = _ffn_f(tgt2, W1, b1, W2, b2, g4, be4, p)                         # :657-659
+            _, st["norm"] = _ln_f(out, gN, beN, out=hs[i])
+            states.append(st)
+        ctx.states = states
+        ctx.prm = prm
+        ctx.gN = gN
+        ctx.mem = (x_mem, x_mp, memory.shape)
+        ctx.dims = (T, D, nl)
+        return hs, ws
 
     @staticmethod
-    def backward(ctx, d_out, d_w):
-        (c_att, st1, c_q1, st3, st4, x_qk, x_v, x_qc, T, D) = ctx.st
-        W_in, Wcq = ctx.Ws
-        d_tgt2, dW1, db1, dW2, db2, dg4, dbe4 = _ffn_b(st4, d_out)
-        d_a2, d_tgt1_res, dWo2, dbo2, dg3, dbe3 = _outln_b(st3, d_tgt2)
-        r = ops.AttnQ1Fn.backward(c_q1, d_a2)
-        dqc, dkc, dvv = r[0], r[2], r[4]
-        d_qcin, dWcq, dBcq, _ = _lin_b(dqc, x_qc, Wcq)           # gradient of (tgt1 + query_pos)
-        d_tgt1 = _add(d_tgt1_res.reshape(T, D), d_qcin)
-        d_a, d_tgt_res, dWo, dbo, dg1, dbe1 = _outln_b(st1, d_tgt1)
-        r = ops.MhaSelfFn.backward(c_att, d_a.view(1, T, D), d_w)
-        dqk, dv = r[0], r[2]
-        dW_in = ops._zeros(d_out, 3 * D, D)
-        dB_in = ops._zeros(d_out, 3 * D)
-        d_t, _, _, _ = _lin_b(dv[0], x_v, W_in[2 * D:], dw=dW_in[2 * D:], db=dB_in[2 * D:], add=d_tgt_res.reshape(T, D))
-        d_qkin, _, _, _ = _lin_b(dqk[0], x_qk, W_in[:2 * D], dw=dW_in[:2 * D], db=dB_in[:2 * D])
-        d_tgt = _add(d_t, d_qkin)
-        return (d_tgt, dkc, dvv, None, d_qcin, d_qkin, None, None, dW_in, dB_in, dWo, dbo, dg1, dbe1, dWcq, dBcq, dWo2,
-                dbo2, dg3, dbe3, dW1, db1, dW2, db2, dg4, dbe4)
+    def backward(ctx, d_hs, d_ws):
+        T, D, nl = ctx.dims
+        prm = ctx.prm
+        x_mem, x_mp, mshape = ctx.mem
+        need_mem, need_qpos = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
+        like = d_hs
+        d_hs = d_hs if d_hs.is_contiguous() else d_hs.contiguous()
+        dgN = ops._zeros(like, D)
+        dbeN = ops._zeros(like, D)
+        d_mem = d_mp = d_qpos = d_qpt = d_next = None
+        d_layers = [None] * nl
+        for i in reversed(range(nl)):
+            st = ctx.states[i]
+            (W_in, B_in, Wo, bo, g1, be1, W_c, B_c, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = \
+                prm[i * _NT_LAYER:(i + 1) * _NT_LAYER]
+            d_out = _ln_b(st["norm"], d_hs[i], dgN, dbeN)
+            if d_next is not None:
+                d_out = _add(d_out, d_next)
+            d_tgt2, dW1, db1, dW2, db2, dg4, dbe4 = _ffn_b(st["ffn"], d_out)
+            d_a2, d_tgt1_res, dWo2, dbo2, dg3, dbe3 = _outln_b(st["o3"], d_tgt2)
+            r = ops.AttnQ1Fn.backward(st["q1"], d_a2)
+            dqc, dkc, dvv = r[0], r[2], r[4]
+            dW_c = ops._zeros(like, 3 * D, D)
+            dB_c = ops._zeros(like, 3 * D)
+            d_mp, _, _, _ = _lin_b(dkc, x_mp, W_c[D:2 * D], need_dx=need_mem, dw=dW_c[D:2 * D], db=dB_c[D:2 * D], add=d_mp)
+            d_mem, _, _, _ = _lin_b(dvv, x_mem, W_c[2 * D:], need_dx=need_mem, dw=dW_c[2 * D:], db=dB_c[2 * D:], add=d_mem)
+            d_qcin, _, _, _ = _lin_b(dqc, st["x_qc"], W_c[:D], dw=dW_c[:D], db=dB_c[:D])     # gradient of (tgt1 + query_pos)
+            d_qpos = d_qcin if d_qpos is None else _add(d_qpos, d_qcin)
+            d_tgt1 = _add(d_tgt1_res.reshape(T, D), d_qcin)
+            d_a, d_out_res, dWo, dbo, dg1, dbe1 = _outln_b(st["o1"], d_tgt1)
+            r = ops.MhaSelfFn.backward(st["att"], d_a.view(1, T, D), d_ws[i] if d_ws is not None else None)
+            dqk, dv = r[0], r[2]
+            dW_in = ops._zeros(like, 3 * D, D)
+            dB_in = ops._zeros(like, 3 * D)
+            first = i == 0                               # layer 0's input state is the constant zero tensor
+            d_t, _, _, _ = _lin_b(dv[0], st["x_v"], W_in[2 * D:], need_dx=not first, dw=dW_in[2 * D:], db=dB_in[2 * D:],
+                                  add=None if first else d_out_res.reshape(T, D))
+            d_qkin, _, _, _ = _lin_b(dqk[0], st["x_qk"], W_in[:2 * D], dw=dW_in[:2 * D], db=dB_in[:2 * D])
+            d_qpt = d_qkin if d_qpt is None else _add(d_qpt, d_qkin)
+            d_next = None if first else _add(d_t, d_qkin)
+            d_layers[i] = (dW_in, dB_in, dWo, dbo, dg1, dbe1, dW_c, dB_c, dWo2, dbo2, dg3, dbe3, dW1, db1, dW2, db2, dg4, dbe4)
+        if need_mem:
+            d_mem = _add(d_mem, d_mp).view(mshape)
+        d_qp = _add(d_qpos, d_qpt) if need_qpos else None
+        flat = ()
+        for t in d_layers:
+            flat += t
+        return (d_mem if need_mem else None, None, None, d_qp, None, None, None, None, dgN, dbeN) + flat
 
 
-def time_decoder_layer(layer, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
-    p = layer.dropout_p if layer.training else 0.0
-    sa, ca = layer.self_attn, layer.cross_attn_image
-    return TimeDecoderLayerFn.apply(tgt, kc, vv, kpm, query_pos, qpos_time, p, layer.nhead, sa.in_proj_weight,
-                                    sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.norm1.weight,
-                                    layer.norm1.bias, Wcq, Bcq, ca.out_proj.weight, ca.out_proj.bias, layer.norm3.weight,
-                                    layer.norm3.bias, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight,
-                                    layer.linear2.bias, layer.norm4.weight, layer.norm4.bias)
+def time_decoder(dec, memory, pos, kpm, query_pos, time_pos):
+    """dec: grounding.TimeDecoder"""
+    p = dec.layers[0].dropout_p if dec.training else 0.0
+    wb = lambda m: (m.weight, m.bias)       # noqa: E731
+    prm = ()
+    for l in dec.layers:
+        sa, ca = l.self_attn, l.cross_attn_image
+        prm += ((sa.in_proj_weight, sa.in_proj_bias) + wb(sa.out_proj) + wb(l.norm1) + (ca.in_proj_weight, ca.in_proj_bias)
+                + wb(ca.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2) + wb(l.norm4))
+    return TimeDecoderFn.apply(memory, pos, kpm, query_pos, time_pos, p, dec.layers[0].nhead, len(dec.layers),
+                               dec.norm.weight, dec.norm.bias, *prm)
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # box decoder: all layers + the anchor-update loop around them (query_decoder.py:150-247, 250-438) as ONE node
 # ------------------------------------------------------------------------------------------------------------------
 _N_SHARED = 16      # ref_point_head (W,b)x2, query_scale (W,b)x2, bbox_embed (W,b)x3, norm (g,b)
-_N_LAYER = 36
-
-
-def _ln_f(x, g, be, out=None):
-    M, D = x.shape
-    y = out if out is not None else torch.empty_like(x)
-    mean = ops._empty(x, M)
-    rstd = ops._empty(x, M)
-    L.call("stcat_layernorm_fwd", x.data_ptr(), None, g.data_ptr(), be.data_ptr(), y.data_ptr(), mean.data_ptr(),
-           rstd.data_ptr(), M, D, 1e-5, 0.0, 0, 0, None, L.stream_of(x))
-    return y, (x, g, mean, rstd)
-
-
-def _ln_b(st, dy, dg, dbe):
-    """dz; dg / dbe accumulate (the kernel adds into caller-zeroed buffers)"""
-    x, g, mean, rstd = st
-    M, D = x.shape
-    dy = dy if dy.is_contiguous() else dy.contiguous()
-    dz = torch.empty_like(x)
-    L.call("stcat_layernorm_bwd", dy.data_ptr(), x.data_ptr(), None, g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-           dz.data_ptr(), None, dg.data_ptr(), dbe.data_ptr(), M, D, 0.0, 0, 0, None, L.stream_of(x))
-    return dz
+_N_LAYER = 42
 
 
 class BoxDecoderFn(Function):
-    """inputs: kc / kp / vv [n,S',L*D] = ca_kcontent_proj(memory), ca_kpos_proj(pos), ca_v_proj(memory) of all layers
-    (TransformerDecoder.memory_projections), kpm, anchor [T,4], time_embed [T,D] -> (hs [L,T,D], refs [L,T,4]).
+    """inputs: memory / pos [n,S',D] (pos: the constant sine embedding), kpm, anchor [T,4], time_embed [T,D] ->
+    (hs [L,T,D], refs [L,T,4]).  Each layer projects the memory itself (ca_kcontent_proj / ca_kpos_proj / ca_v_proj,
+    query_decoder.py:355-358), so the key / value gradients feed that layer's weight and data gradients directly.
     Shared modules (ref_point_head, query_scale, bbox_embed, norm) accumulate their gradients over the layers inside
     the node instead of through L AccumulateGrad adds."""
 
     @staticmethod
-    def forward(ctx, kc, kp, vv, kpm, anchor, time_embed, p, nhead, nl, *prm):
+    def forward(ctx, memory, pos, kpm, anchor, time_embed, p, nhead, nl, *prm):
         T = anchor.shape[0]
+        memory = memory if memory.is_contiguous() else memory.contiguous()
+        pos = pos if pos.is_contiguous() else pos.contiguous()
         D = time_embed.shape[1]
         hd = D // nhead
         sh = prm[:_N_SHARED]
@@ -315,7 +373,7 @@ class BoxDecoderFn(Function):
         for i in range(nl):
             lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]
             (Wqc, bqc, Wqp, bqp, Wqt, bqt, Wkc, bkc, Wkp, bkp, Wkt, bkt, Wv, bv, W_in, B_in, Wo, bo, g1, be1, Wcq, bcq,
-             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = lp
+             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4, Wmk, bmk, Wmp, bmp, Wmv, bmv) = lp
             first = i == 0
             st = {}
             sine, st["sine"] = _f(ops.SineEmbedFn, _T, anchor)                                # [T,512]  :190
@@ -347,11 +405,13 @@ class BoxDecoderFn(Function):
             st["sa_in"] = (out, qpos, q, k, v)
             # ---- time-aligned cross-attention :355-432
             qc, _ = _lin_f(tgt1, Wcq, bcq)
-            kci, kpi, vvi = kc[..., i * D:(i + 1) * D], kp[..., i * D:(i + 1) * D], vv[..., i * D:(i + 1) * D]
+            kpi, x_pos = _lin_f(pos, Wmp, bmp)                                                # :355-358
+            vvi, x_mem = _lin_f(memory, Wmv, bmv)
             if first:                                                                        # :360-366
                 qc, _ = _lin_f(qpos, Wcqp, bcqp, res=qc)
-                kpi = ops.ew2d(L.EW_COPY, kpi)          # k1 and k2 must share one leading dimension in the kernel
-                kci = ops.ew2d(L.EW_ADD, kci, kpi)
+                kci, _ = _lin_f(memory, Wmk, bmk, res=kpi)
+            else:
+                kci, _ = _lin_f(memory, Wmk, bmk)
             qs, st["x_qs"] = _lin_f(sine_q, Wqs, bqs)                                        # :369
             a2, st["q1"] = _f(ops.AttnQ1Fn, _T, qc, qs, kci, kpi, vvi, kpm, (2 * hd) ** -0.5, p)
             tgt2, st["o3"] = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)
@@ -372,15 +432,19 @@ class BoxDecoderFn(Function):
         ctx.states = states
         ctx.prm = prm
         ctx.time_embed = time_embed
-        ctx.dims = (T, D, nl, kc.shape)
+        ctx.mem = (x_mem, x_pos, memory.shape)
+        ctx.dims = (T, D, nl)
         ctx.refs = refs
         return hs, ops.ew(L.EW_COPY, refs)       # (a copy: the node keeps `refs`, and an output held by its own node is a cycle)
 
     @staticmethod
     def backward(ctx, d_hs, d_refs):
-        T, D, nl, kshape = ctx.dims
+        T, D, nl = ctx.dims
         prm, refs = ctx.prm, ctx.refs
-        need_anchor = ctx.needs_input_grad[4]
+        x_mem, x_pos, mshape = ctx.mem
+        need_anchor = ctx.needs_input_grad[3]
+        need_mem = ctx.needs_input_grad[0]
+        d_mem = None
         (Wr1, br1, Wr2, br2, Ws1, bs1, Ws2, bs2, Wb1, bb1, Wb2, bb2, Wb3, bb3, gN, beN) = prm[:_N_SHARED]
         like = d_hs
         z = lambda t: ops._zeros(like, *t.shape)      # noqa: E731
@@ -389,9 +453,6 @@ class BoxDecoderFn(Function):
         d_hs = d_hs if d_hs.is_contiguous() else d_hs.contiguous()
         if d_refs is not None and not d_refs.is_contiguous():
             d_refs = d_refs.contiguous()
-        d_kc = ops._empty(like, *kshape)
-        d_kp = ops._empty(like, *kshape)
-        d_vv = ops._empty(like, *kshape)
         d_layers = [None] * nl
         d_anchor = None
         d_next = None                                  # gradient reaching layer i's output state from layer i+1
@@ -399,7 +460,7 @@ class BoxDecoderFn(Function):
             st = ctx.states[i]
             lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]
             (Wqc, bqc, Wqp, bqp, Wqt, bqt, Wkc, bkc, Wkp, bkp, Wkt, bkt, Wv, bv, W_in, B_in, Wo, bo, g1, be1, Wcq, bcq,
-             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4) = lp
+             Wcqp, bcqp, Wqs, bqs, Wo2, bo2, g3, be3, W1, b1, W2, b2, g4, be4, Wmk, bmk, Wmp, bmp, Wmv, bmv) = lp
             first = i == 0
             d_out = _ln_b(st["norm"], d_hs[i], dgN, dbeN)
             if d_next is not None:
@@ -418,13 +479,9 @@ class BoxDecoderFn(Function):
             d_a2, d_tgt1_res, dWo2, dbo2, dg3, dbe3 = _outln_b(st["o3"], d_tgt2)
             r = ops.AttnQ1Fn.backward(st["q1"], d_a2)
             dqc, dqs, dk1, dk2, dvv_i = r[0], r[1], r[2], r[3], r[4]
-            cs = slice(i * D, (i + 1) * D)
-            ops.ew2d(L.EW_COPY, dk1, out=d_kc[..., cs])
-            if first:
-                ops.ew2d(L.EW_ADD, dk1, dk2, out=d_kp[..., cs])
-            else:
-                ops.ew2d(L.EW_COPY, dk2, out=d_kp[..., cs])
-            ops.ew2d(L.EW_COPY, dvv_i, out=d_vv[..., cs])
+            d_mem, dWmk, dbmk, _ = _lin_b(dk1, x_mem, Wmk, need_dx=need_mem, add=d_mem)
+            d_mem, dWmv, dbmv, _ = _lin_b(dvv_i, x_mem, Wmv, need_dx=need_mem, add=d_mem)
+            _, dWmp, dbmp, _ = _lin_b(_add(dk1, dk2) if first else dk2, x_pos, Wmp, need_dx=False)
             d_sine_q, dWqs, dbqs, _ = _lin_b(dqs, st["x_qs"], Wqs, need_dx=(not first) or need_anchor)
             d_qpos = None
             dWcqp = dbcqp = None
@@ -463,15 +520,15 @@ class BoxDecoderFn(Function):
             d_next = d_x
             d_layers[i] = (dWqc, dbqc, dWqp, dbqp, dWqt, dbqt, dWkc, dbkc, dWkp, dbkp, dWkt, dbkt, dWv, dbv, dW_in, dB_in,
                            dWo, dbo, dg1, dbe1, dWcq, dbcq, dWcqp, dbcqp, dWqs, dbqs, dWo2, dbo2, dg3, dbe3, dW1, db1,
-                           dW2, db2, dg4, dbe4)
+                           dW2, db2, dg4, dbe4, dWmk, dbmk, dWmp, dbmp, dWmv, dbmv)
         flat = tuple(d_sh)
         for t in d_layers:
             flat += t
-        return (d_kc, d_kp, d_vv, None, d_anchor, None, None, None, None) + flat
+        return ((d_mem.view(mshape) if d_mem is not None else None), None, None, d_anchor, None, None, None, None) + flat
 
 
-def box_decoder(dec, kc, kp, vv, kpm, anchor, time_embed):
-    """dec: grounding.TransformerDecoder; kc/kp/vv: the layer-batched memory projections [n,S',L*D]"""
+def box_decoder(dec, memory, pos, kpm, anchor, time_embed):
+    """dec: grounding.TransformerDecoder"""
     p = dec.layers[0].dropout_p if dec.training else 0.0
     wb = lambda m: (m.weight, m.bias)       # noqa: E731
     prm = (wb(dec.ref_point_head.layers[0]) + wb(dec.ref_point_head.layers[1]) + wb(dec.query_scale.layers[0])
@@ -484,5 +541,5 @@ def box_decoder(dec, kc, kp, vv, kpm, anchor, time_embed):
                 + (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias) + wb(l.norm1)
                 + wb(l.ca_qcontent_proj) + (wb(l.ca_qpos_proj) if l.ca_qpos_proj is not None else (None, None))
                 + wb(l.ca_qpos_sine_proj) + wb(l.cross_attn.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2)
-                + wb(l.norm4))
-    return BoxDecoderFn.apply(kc, kp, vv, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)
+                + wb(l.norm4) + wb(l.ca_kcontent_proj) + wb(l.ca_kpos_proj) + wb(l.ca_v_proj))
+    return BoxDecoderFn.apply(memory, pos, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)

@@ -299,23 +299,21 @@ class TransformerDecoder(nn.Module):
         for layer_id in range(num_layers - 1):
             self.layers[layer_id + 1].ca_qpos_proj = None                                    # :166-167
 
-    def memory_projections(self, memory, pos, split=True):
+    def memory_projections(self, memory, pos):
         """ca_kcontent_proj / ca_v_proj of `memory` and ca_kpos_proj of `pos` for ALL layers as three GEMMs
         with N = layers*256 (query_decoder.py:355-358 computes them layer by layer on the same inputs)."""
         L_ = self.num_layers
         cat = lambda nm, leaf: torch.cat([getattr(getattr(l, nm), leaf) for l in self.layers], dim=0)  # noqa: E731
-        kc = ops.linear(memory, cat("ca_kcontent_proj", "weight"), cat("ca_kcontent_proj", "bias"))
-        vv = ops.linear(memory, cat("ca_v_proj", "weight"), cat("ca_v_proj", "bias"))
-        kp = ops.linear(pos, cat("ca_kpos_proj", "weight"), cat("ca_kpos_proj", "bias"))
-        if not split:
-            return kc, kp, vv
-        return ops.split_cols(kc, L_), ops.split_cols(kp, L_), ops.split_cols(vv, L_)
+        kc = ops.split_cols(ops.linear(memory, cat("ca_kcontent_proj", "weight"), cat("ca_kcontent_proj", "bias")), L_)
+        vv = ops.split_cols(ops.linear(memory, cat("ca_v_proj", "weight"), cat("ca_v_proj", "bias")), L_)
+        kp = ops.split_cols(ops.linear(pos, cat("ca_kpos_proj", "weight"), cat("ca_kpos_proj", "bias")), L_)
+        return kc, kp, vv
 
     def run(self, memory, kpm, pos, anchor, time_embed):
         """memory/pos [n,S',256]; anchor [T,4] (sigmoid-ed template); returns hs [L,T,256], refs [L,T,4]."""
         T = anchor.shape[0]
         if composite.ENABLED:
-            return composite.box_decoder(self, *self.memory_projections(memory, pos, split=False), kpm, anchor, time_embed)
+            return composite.box_decoder(self, memory, pos, kpm, anchor, time_embed)
         kc, kp, vv = self.memory_projections(memory, pos)
         out = torch.zeros(T, self.d_model, device=memory.device)
         inter, refs = [], [anchor]
@@ -353,8 +351,6 @@ class TimeDecoderLayer(nn.Module):
     def run(self, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq):
         """kc/vv [n,S',256]: this layer's key / value in-projection of (memory + pos) / memory; Wcq/Bcq: the query
         rows of cross_attn_image's packed in-projection (split once in TimeDecoder.run)."""
-        if composite.ENABLED:
-            return composite.time_decoder_layer(self, tgt, kc, vv, kpm, query_pos, qpos_time, Wcq, Bcq)
         T, D = tgt.shape
         hd = D // self.nhead
         p = self.dropout_p if self.training else 0.0
@@ -441,9 +437,13 @@ class QueryDecoder(nn.Module):
         # overlap on the GPU.  Autograd replays each backward node on its forward stream, so backward overlaps too.
         fork = ops.fork_stream(memory)
         with fork:
-            mem_plus_pos = ops.add_const(memory, mem_pos)                                    # memory + pos  :636
-            time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(),
-                                                     time_embed)
+            if composite.ENABLED:
+                time_hs, weights = composite.time_decoder(self.temp_decoder, memory, mem_pos, mem_kpm, temp_query,
+                                                          time_embed)
+            else:
+                mem_plus_pos = ops.add_const(memory, mem_pos)                                # memory + pos  :636
+                time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(),
+                                                         time_embed)
         hs, ref = self.decoder.run(memory, mem_kpm, mem_pos, anchor, time_embed)
         fork.join(time_hs, weights)
         return hs, ref, time_hs, weights, pos_query
