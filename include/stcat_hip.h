@@ -179,7 +179,8 @@ int stcat_ew(int op, const float* a, const float* b, const float* c, float* out,
              float beta, void* stream);
 /* row-strided two-operand form (ADD, MUL, AXPBY, COPY): out[r*ldo + c] = op(a[r*lda + c], b[r*ldb + c]); column blocks of
  * wider matrices (a decoder layer's slice of the layer-batched key/value projections, query_decoder.py:355-358; the
- * first half of the anchor sine embedding, query_decoder.py:193-200) without a gather copy */
+ * first half of the anchor sine embedding, query_decoder.py:193-200) without a gather copy.  lda / ldb == 0 broadcasts
+ * one row (the [CLS] embeddings prepended to every frame's tokens, modal_encoder.py:145-151) */
 int stcat_ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int cols,
                float alpha, float beta, void* stream);
 enum {
@@ -251,6 +252,28 @@ int stcat_map2d_cells(const float* pooled, const int* cell_i, const int* cell_j,
                       void* stream);
 /* y[m, :] *= w[m % period]: the per-pixel mask-normalisation weight after each conv + ReLU (:247-249) */
 int stcat_rowscale(float* y, const float* w, long rows, int C, int period, void* stream);
+
+/* ---- VideoSTGLoss (models/criterion.py:11-208), all decoder layers in one launch --------------------------------
+ * vec[k*nl + l] = un-weighted loss k of decoder layer l; k = 0 loss_bbox (criterion.py:38-55), 1 loss_giou (:56-66),
+ * 2 loss_sted (:68-124), 3 loss_guided_attn (:126-145), 4 loss_actioness (:147-158; 0 when act == NULL).
+ * boxes [nl][rows_total][4] (cx,cy,w,h); rows [nbox] = the GT-span rows (:168-171); tgt [nbox][4]; sted [nl][b][T][2];
+ * dist [b][T][2] the normalised Gaussian span targets; time_mask / pos_or_pad [b][T] bytes; w [nl][b][T][T];
+ * nb_neg [b]; act [nl][b][T] with act_tgt / act_w [b][T].  num_boxes: host value, or a device scalar (the
+ * data-parallel mean box count, :175-178) when num_boxes_dev != NULL.  wmat [5][nl] (may be NULL): weight_dict laid
+ * out like vec; total (may be NULL, caller-zeroed) += sum wmat * vec. */
+int stcat_stg_loss_fwd(const float* boxes, const long* rows, const float* tgt, const float* sted, const float* dist,
+                       const unsigned char* time_mask, const float* w, const unsigned char* pos_or_pad,
+                       const float* nb_neg, const float* act, const float* act_tgt, const float* act_w,
+                       const float* num_boxes_dev, float num_boxes, int nl, int rows_total, int nbox, int b, int T,
+                       const float* wmat, float* vec, float* total, void* stream);
+/* gradients of sum_k,l (gvec[k][l] + gtotal * wmat[k][l]) * vec[k][l] w.r.t. boxes / sted / w / act (same shapes; the
+ * rows of d_boxes outside the GT span are written as zeros).  gvec or gtotal may be NULL. */
+int stcat_stg_loss_bwd(const float* boxes, const long* rows, const float* tgt, const float* sted, const float* dist,
+                       const unsigned char* time_mask, const float* w, const unsigned char* pos_or_pad,
+                       const float* nb_neg, const float* act, const float* act_tgt, const float* act_w,
+                       const float* num_boxes_dev, float num_boxes, int nl, int rows_total, int nbox, int b, int T,
+                       const float* wmat, const float* gvec, const float* gtotal, float* d_boxes, float* d_sted,
+                       float* d_w, float* d_act, void* stream);
 
 /* ---- optimizer tail (scripts/train_net.py:134-143) ------------------------------------------------ */
 /* Multi-tensor launches over a DEVICE table of entries

@@ -43,6 +43,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_layernorm_bwd": "ppppppppppii" + "fllps",
     "stcat_ew": "ipppp" + "llffs",
     "stcat_ew2d": "iplplpllif" + "fs",
+    "stcat_stg_loss_fwd": "p" * 13 + "f" + "iiiii" + "ppp" + "s",
+    "stcat_stg_loss_bwd": "p" * 13 + "f" + "iiiii" + "ppp" + "pppp" + "s",
     "stcat_dropout": "ppplfllps",
     "stcat_mha_self_fwd": "ppppppiiiiiiif" + "fllps",
     "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "fllps",

@@ -543,3 +543,115 @@ def box_decoder(dec, memory, pos, kpm, anchor, time_embed):
                 + wb(l.ca_qpos_sine_proj) + wb(l.cross_attn.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2)
                 + wb(l.norm4) + wb(l.ca_kcontent_proj) + wb(l.ca_kpos_proj) + wb(l.ca_v_proj))
     return BoxDecoderFn.apply(memory, pos, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# spatial-temporal encoder (modal_encoder.py:70-82, 104-204): token assembly + 2 x L layers as ONE node
+# ------------------------------------------------------------------------------------------------------------------
+_NE_LAYER = 12
+
+
+def _cols(t3, r0, r1):
+    """rows r0..r1 of every frame of a contiguous [n, S, d] tensor as a row-strided 2-D block [n, (r1-r0)*d]"""
+    n, S, d = t3.shape
+    return t3.view(n, S * d)[:, r0 * d:r1 * d]
+
+
+class EncoderFn(Function):
+    """inputs: vis_tokens [n,HW,d], txt [L,d], vis_pos [n,HW,d] (constant), kpm [n,1+HW+L] (bytes; column 0 = the frame
+    [CLS] slot), tpos [1,n+1,d] (constant) -> (memory [n,HW+L,d], frames_cls [n,d], video_cls [1,d]).
+    The reference concatenates / re-slices the token matrix around every layer (:145-151, :170-177, :195); here one
+    buffer [n, 1+HW+L, d] is assembled once, the temporal layer's rows are written back into its [CLS] slots in place
+    (as the reference's `src[0] = ...` does) and the backward routes those slots' gradients the same way."""
+
+    @staticmethod
+    def forward(ctx, vis_tokens, txt, vis_pos, kpm, tpos, p, nhead, nl, frame_cls, local_pos, video_cls, *prm):
+        n, HW, d = vis_tokens.shape
+        Lt = txt.shape[0]
+        S1 = 1 + HW + Lt
+        vis_tokens = vis_tokens if vis_tokens.is_contiguous() else vis_tokens.contiguous()
+        txt = txt if txt.is_contiguous() else txt.contiguous()
+        vis_pos = vis_pos if vis_pos.is_contiguous() else vis_pos.contiguous()
+        x = ops._empty(vis_tokens, n, S1, d)
+        ops.ew2d(L.EW_COPY, frame_cls.view(1, d), out=_cols(x, 0, 1))                          # :145-149
+        ops.ew2d(L.EW_COPY, vis_tokens.view(n, HW * d), out=_cols(x, 1, 1 + HW))
+        ops.ew2d(L.EW_COPY, txt.view(1, Lt * d), out=_cols(x, 1 + HW, S1))                      # :70-80
+        pos = ops._zeros(vis_tokens, n, S1, d)                                                 # :82, :151
+        ops.ew2d(L.EW_COPY, local_pos.view(1, d), out=_cols(pos, 0, 1))
+        ops.ew2d(L.EW_COPY, vis_pos.view(n, HW * d), out=_cols(pos, 1, 1 + HW))
+        video = video_cls.view(1, d)
+        ctxs = []
+        for i in range(nl):
+            sp = prm[(2 * i) * _NE_LAYER:(2 * i + 1) * _NE_LAYER]
+            tp = prm[(2 * i + 1) * _NE_LAYER:(2 * i + 2) * _NE_LAYER]
+            c_s = _Ctx((True, True))
+            x1 = EncoderLayerFn.forward(c_s, x, pos, kpm, p, nhead, *sp)                       # :163-168
+            seq = ops._empty(x, 1, n + 1, d)                                                   # :170-177
+            ops.ew(L.EW_COPY, video, out=seq[0, 0:1])
+            ops.ew2d(L.EW_COPY, _cols(x1, 0, 1), out=seq[0, 1:])
+            c_t = _Ctx((True, False))
+            seq2 = EncoderLayerFn.forward(c_t, seq, tpos, None, p, nhead, *tp)                 # :180-185
+            video = seq2[0, 0:1]                                                               # :190
+            ops.ew2d(L.EW_COPY, seq2[0, 1:], out=_cols(x1, 0, 1))                              # :195 (in place there too)
+            x = x1
+            ctxs.append((c_s, c_t))
+        ctx.ctxs = ctxs
+        ctx.dims = (n, HW, Lt, d, nl)
+        memory = ops.ew2d(L.EW_COPY, _cols(x, 1, S1)).view(n, S1 - 1, d)
+        frames = ops.ew2d(L.EW_COPY, _cols(x, 0, 1))
+        return memory, frames, ops.ew(L.EW_COPY, video)
+
+    @staticmethod
+    def backward(ctx, d_memory, d_frames, d_video):
+        n, HW, Lt, d, nl = ctx.dims
+        S1 = 1 + HW + Lt
+        like = d_memory if d_memory is not None else (d_frames if d_frames is not None else d_video)
+        d_x = ops._zeros(like, n, S1, d) if (d_memory is None or d_frames is None) else ops._empty(like, n, S1, d)
+        if d_memory is not None:
+            ops.ew2d(L.EW_COPY, d_memory.contiguous().view(n, (S1 - 1) * d), out=_cols(d_x, 1, S1))
+        if d_frames is not None:
+            ops.ew2d(L.EW_COPY, d_frames.contiguous(), out=_cols(d_x, 0, 1))
+        d_video = d_video.contiguous().view(1, d) if d_video is not None else ops._zeros(like, 1, d)
+        d_lp = None                                   # [n,d] gradient rows of the [CLS] position embedding, all layers
+        grads = [None] * (2 * nl)
+        for i in reversed(range(nl)):
+            c_s, c_t = ctx.ctxs[i]
+            d_seq2 = ops._empty(like, 1, n + 1, d)
+            ops.ew(L.EW_COPY, d_video, out=d_seq2[0, 0:1])
+            ops.ew2d(L.EW_COPY, _cols(d_x, 0, 1), out=d_seq2[0, 1:])
+            r = EncoderLayerFn.backward(c_t, d_seq2)
+            grads[2 * i + 1] = r[5:]
+            d_seq = r[0]
+            d_video = d_seq[0, 0:1]
+            ops.ew2d(L.EW_COPY, d_seq[0, 1:], out=_cols(d_x, 0, 1))       # the [CLS] slots of x1 fed the temporal layer
+            r = EncoderLayerFn.backward(c_s, d_x)
+            grads[2 * i] = r[5:]
+            d_x, d_pos = r[0], r[1]
+            if d_lp is None:
+                d_lp = ops.ew2d(L.EW_COPY, _cols(d_pos, 0, 1))
+            else:
+                ops.ew2d(L.EW_ADD, d_lp, _cols(d_pos, 0, 1), out=d_lp)
+        ni = ctx.needs_input_grad
+        d_vis = ops.ew2d(L.EW_COPY, _cols(d_x, 1, 1 + HW)).view(n, HW, d) if ni[0] else None
+        d_txt = None
+        if ni[1]:
+            d_txt = ops.colsum(ops.ew2d(L.EW_COPY, _cols(d_x, 1 + HW, S1))).view(Lt, d)
+        d_fc = ops.colsum(ops.ew2d(L.EW_COPY, _cols(d_x, 0, 1))).view(1, d)
+        flat = ()
+        for g in grads:
+            flat += tuple(g)
+        return (d_vis, d_txt, None, None, None, None, None, None, d_fc, ops.colsum(d_lp).view(1, d),
+                ops.ew(L.EW_COPY, d_video)) + flat
+
+
+def encoder(enc, vis_tokens, txt, vis_pos, kpm_full, tpos):
+    """enc: grounding.SpatialTemporalEncoder"""
+    p = enc.spatial_layers[0].dropout_p if enc.training else 0.0
+    prm = ()
+    for i in range(enc.num_layers):
+        for l in (enc.spatial_layers[i], enc.temporal_layers[i]):
+            sa = l.self_attn
+            prm += (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, l.norm1.weight, l.norm1.bias,
+                    l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias)
+    return EncoderFn.apply(vis_tokens, txt, vis_pos, kpm_full, tpos, p, enc.spatial_layers[0].nhead, enc.num_layers,
+                           enc.frame_cls.weight, enc.local_pos_embed.weight, enc.video_cls.weight, *prm)

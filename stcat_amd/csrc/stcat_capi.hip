@@ -12,6 +12,7 @@
 #include "igemm_bs.h"
 #include "igemm_pl.h"
 #include "pointwise.h"
+#include "loss.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -671,12 +672,63 @@ int stcat_ew(int op, const float* a, const float* b, const float* c, float* out,
   return launch_status();
 }
 
+static int stg_loss_fill(StgLossParams& q, const float* boxes, const long* rows, const float* tgt, const float* sted,
+                         const float* dist, const unsigned char* time_mask, const float* w, const unsigned char* pos_or_pad,
+                         const float* nb_neg, const float* act, const float* act_tgt, const float* act_w,
+                         const float* num_boxes_dev, float num_boxes, int nl, int rows_total, int nbox, int b, int T,
+                         const float* wmat) {
+  if (nl <= 0 || b <= 0 || T <= 0 || nbox < 0 || rows_total <= 0) return fail("stg_loss: nl=%d b=%d T=%d nbox=%d rows=%d", nl, b, T, nbox, rows_total);
+  if (!boxes || !tgt || !sted || !dist || !time_mask || !w || !pos_or_pad || !nb_neg) return fail("stg_loss: NULL operand");
+  if (nbox > 0 && !rows) return fail("stg_loss: rows is NULL");
+  if (act && (!act_tgt || !act_w)) return fail("stg_loss: actioness logits without targets / weights");
+  if (!num_boxes_dev && !(num_boxes > 0.f)) return fail("stg_loss: num_boxes=%f", (double)num_boxes);
+  if (!aligned16(boxes) || !aligned16(tgt)) return fail("stg_loss: boxes / targets must be 16-byte aligned");
+  q = StgLossParams{};
+  q.boxes = boxes; q.rows = rows; q.tgt = tgt; q.sted = sted; q.dist = dist; q.time_mask = time_mask; q.w = w;
+  q.pos_or_pad = pos_or_pad; q.nb_neg = nb_neg; q.act = act; q.act_tgt = act_tgt; q.act_w = act_w;
+  q.num_boxes_dev = num_boxes_dev; q.num_boxes = num_boxes; q.nl = nl; q.rows_total = rows_total; q.nbox = nbox; q.b = b;
+  q.T = T; q.wmat = wmat;
+  return 0;
+}
+
+int stcat_stg_loss_fwd(const float* boxes, const long* rows, const float* tgt, const float* sted, const float* dist,
+                       const unsigned char* time_mask, const float* w, const unsigned char* pos_or_pad,
+                       const float* nb_neg, const float* act, const float* act_tgt, const float* act_w,
+                       const float* num_boxes_dev, float num_boxes, int nl, int rows_total, int nbox, int b, int T,
+                       const float* wmat, float* vec, float* total, void* stream) {
+  StgLossParams q;
+  if (int e = stg_loss_fill(q, boxes, rows, tgt, sted, dist, time_mask, w, pos_or_pad, nb_neg, act, act_tgt, act_w,
+                            num_boxes_dev, num_boxes, nl, rows_total, nbox, b, T, wmat)) return e;
+  if (!vec) return fail("stg_loss_fwd: vec is NULL");
+  if (total && !wmat) return fail("stg_loss_fwd: total needs the weight matrix");
+  q.vec = vec; q.total = total;
+  STCAT_LAUNCH(stg_loss_fwd_kernel, dim3(nl), dim3(256), 0, (hipStream_t)stream, q);
+  return launch_status();
+}
+
+int stcat_stg_loss_bwd(const float* boxes, const long* rows, const float* tgt, const float* sted, const float* dist,
+                       const unsigned char* time_mask, const float* w, const unsigned char* pos_or_pad,
+                       const float* nb_neg, const float* act, const float* act_tgt, const float* act_w,
+                       const float* num_boxes_dev, float num_boxes, int nl, int rows_total, int nbox, int b, int T,
+                       const float* wmat, const float* gvec, const float* gtotal, float* d_boxes, float* d_sted,
+                       float* d_w, float* d_act, void* stream) {
+  StgLossParams q;
+  if (int e = stg_loss_fill(q, boxes, rows, tgt, sted, dist, time_mask, w, pos_or_pad, nb_neg, act, act_tgt, act_w,
+                            num_boxes_dev, num_boxes, nl, rows_total, nbox, b, T, wmat)) return e;
+  if (!gvec && !(gtotal && wmat)) return fail("stg_loss_bwd: no incoming gradient (gvec, or gtotal with the weight matrix)");
+  if (!d_boxes || !d_sted || !d_w || (act && !d_act)) return fail("stg_loss_bwd: NULL gradient output");
+  q.gvec = gvec; q.gtotal = gtotal; q.d_boxes = d_boxes; q.d_sted = d_sted; q.d_w = d_w; q.d_act = d_act;
+  STCAT_LAUNCH(stg_loss_bwd_kernel, dim3(nl), dim3(256), 0, (hipStream_t)stream, q);
+  return launch_status();
+}
+
 int stcat_ew2d(int op, const float* a, long lda, const float* b, long ldb, float* out, long ldo, long rows, int cols,
                float alpha, float beta, void* stream) {
   if (rows <= 0 || cols <= 0) return fail("ew2d: rows=%ld cols=%d", rows, cols);
   if (op != EW_ADD && op != EW_MUL && op != EW_AXPBY && op != EW_COPY) return fail("ew2d: op %d is not a two-operand op / copy", op);
   if (op != EW_COPY && !b) return fail("ew2d: op %d needs b", op);
-  if (lda < cols || ldo < cols || (b && ldb < cols)) return fail("ew2d: leading dimension below cols");
+  // lda / ldb == 0: one row broadcast to every output row
+  if ((lda && lda < cols) || ldo < cols || (b && ldb && ldb < cols)) return fail("ew2d: leading dimension below cols");
   STCAT_LAUNCH(ew2d_kernel, dim3(grid_for(rows * cols, 256, 4096)), dim3(256), 0, (hipStream_t)stream, op, a, lda, b, ldb,
                out, ldo, rows, cols, alpha, beta);
   return launch_status();

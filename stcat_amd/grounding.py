@@ -179,6 +179,20 @@ class CrossModalEncoder(nn.Module):
         """vis_tokens/vis_pos [n,HW,256], vis_mask [n,HW] bool, text_mask [1,L] bool, text_mem [L,1,256]."""
         n, hw, d = vis_tokens.shape
         L = text_mem.shape[0]
+        if composite.ENABLED:
+            # masks (bytes, 1 = padding): column 0 = the frame [CLS] slot the encoder prepends (:147), then the visual
+            # tokens with token 0 forced valid (:46), then the text; built once, shared by all 24 attention layers
+            full = torch.zeros(n, 1 + hw + L, dtype=torch.uint8, device=vis_tokens.device)
+            full[:, 1:1 + hw] = vis_mask
+            full[:, 1] = 0
+            full[:, 1 + hw:] = text_mask[0:1]
+            mask = full[:, 1:].contiguous()
+            pos = ops._zeros(vis_tokens, n, hw + L, d)                                       # :82
+            ops.ew2d(ops.L.EW_COPY, vis_pos.contiguous().view(n, hw * d), out=pos.view(n, (hw + L) * d)[:, :hw * d])
+            tpos = self.encoder.time_embed(n + 1)[:, 0, :][None]                             # [1,n+1,256] :155
+            memory, frames_cls, video_cls = composite.encoder(self.encoder, vis_tokens, text_mem[:, 0, :], vis_pos,
+                                                              full, tpos)
+            return memory, mask, frames_cls, video_cls, pos
         vis_mask = vis_mask.clone()
         vis_mask[:, 0] = False                                                               # :46
         txt = text_mem[:, 0, :][None].expand(n, L, d)                                        # :70-77
@@ -198,7 +212,7 @@ class CrossModalEncoder(nn.Module):
         memory, mask, frames_cls, video_cls, _ = self.run(
             feat.flatten(2).transpose(1, 2), vis_mask.flatten(1), vis_pos.flatten(2).transpose(1, 2),
             text_mask, text_mem)
-        return {"encoded_memory": memory.transpose(0, 1), "mask": mask, "frames_cls": frames_cls,
+        return {"encoded_memory": memory.transpose(0, 1), "mask": mask.bool(), "frames_cls": frames_cls,
                 "videos_cls": video_cls, "durations": durations, "fea_map_size": (H, W)}
 
 

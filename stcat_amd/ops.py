@@ -176,8 +176,12 @@ def ew2d(op: int, a, b=None, out=None, alpha: float = 1.0, beta: float = 1.0):
     o2 = rows(ret)
     assert o2.data_ptr() == ret.data_ptr()
     _chk(a2, b2)
-    L.call("stcat_ew2d", op, a2.data_ptr(), a2.stride(0), L._ptr(b2), (b2.stride(0) if b2 is not None else 0), o2.data_ptr(),
-           o2.stride(0), a2.shape[0], C, alpha, beta, L.stream_of(a2))
+    R = o2.shape[0]            # a one-row operand is broadcast over the output rows (leading dimension 0)
+    lda = a2.stride(0) if a2.shape[0] == R else 0
+    ldb = 0 if b2 is None or b2.shape[0] != R else b2.stride(0)
+    assert a2.shape[0] in (1, R) and (b2 is None or b2.shape[0] in (1, R))
+    L.call("stcat_ew2d", op, a2.data_ptr(), lda, L._ptr(b2), ldb, o2.data_ptr(), o2.stride(0), R, C, alpha, beta,
+           L.stream_of(a2))
     return ret
 
 
@@ -215,6 +219,57 @@ def act_bwd_raw(dy, y, scale, want_g=True, want_res=False, relu=True):
     L.call("stcat_act_bwd", dy.data_ptr(), L._ptr(y), L._ptr(scale), L._ptr(G), L._ptr(R), n, C, int(relu),
            L.stream_of(dy))
     return G, R
+
+
+# ------------------------------------------------------------------------------------
+# VideoSTGLoss: all decoder layers, all five terms, one launch each way (csrc/loss.h)
+# ------------------------------------------------------------------------------------
+LOSS_ROWS = ("loss_bbox", "loss_giou", "loss_sted", "loss_guided_attn", "loss_actioness")
+
+
+class StgLossFn(Function):
+    """(boxes [nl,rows,4], sted [nl,b,T,2], weights [nl,b,T,T], act [nl,b,T]|None, plan, wmat [5,nl]|None) ->
+    (vec [5,nl] un-weighted losses per layer, total = sum wmat*vec | None) — models/criterion.py:11-208."""
+
+    @staticmethod
+    def _args(boxes, sted, w, act, plan):
+        nl, rows_total = boxes.shape[0], boxes.shape[1]
+        nb = plan.num_boxes(boxes.device)
+        nb_dev = nb if torch.is_tensor(nb) else None
+        return (boxes.data_ptr(), plan.rows.data_ptr(), plan.tgt_boxes.data_ptr(), sted.data_ptr(), plan.dist.data_ptr(),
+                plan.time_mask_u8.data_ptr(), w.data_ptr(), plan.pos_or_pad_u8.data_ptr(), plan.nb_neg.data_ptr(),
+                L._ptr(act), plan.actioness.data_ptr(), plan.act_weight.data_ptr(), L._ptr(nb_dev),
+                0.0 if nb_dev is not None else float(nb), nl, rows_total, plan.rows.numel(), plan.b, plan.T)
+
+    @staticmethod
+    def forward(ctx, boxes, sted, w, act, plan, wmat):
+        boxes, sted, w, act = _c(boxes), _c(sted), _c(w), _c(act)
+        _chk(boxes, sted, w, act, wmat)
+        nl = boxes.shape[0]
+        assert sted.shape == (nl, plan.b, plan.T, 2) and w.shape == (nl, plan.b, plan.T, plan.T)
+        vec = _empty(boxes, 5, nl)
+        total = _zeros(boxes, 1) if wmat is not None else None
+        L.call("stcat_stg_loss_fwd", *StgLossFn._args(boxes, sted, w, act, plan), L._ptr(wmat), vec.data_ptr(), L._ptr(total),
+               L.stream_of(boxes))
+        ctx.save_for_backward(boxes, sted, w, act, wmat)
+        ctx.plan = plan
+        ctx.set_materialize_grads(False)
+        if total is None:
+            ctx.mark_non_differentiable()
+            return vec, None
+        return vec, total.view(())
+
+    @staticmethod
+    def backward(ctx, gvec, gtotal):
+        boxes, sted, w, act, wmat = ctx.saved_tensors
+        if gvec is None and gtotal is None:
+            return None, None, None, None, None, None
+        gvec, gtotal = _c(gvec), _c(gtotal)
+        d_boxes, d_sted, d_w = torch.empty_like(boxes), torch.empty_like(sted), torch.empty_like(w)
+        d_act = torch.empty_like(act) if act is not None else None
+        L.call("stcat_stg_loss_bwd", *StgLossFn._args(boxes, sted, w, act, ctx.plan), L._ptr(wmat), L._ptr(gvec),
+               L._ptr(gtotal), d_boxes.data_ptr(), d_sted.data_ptr(), d_w.data_ptr(), L._ptr(d_act), L.stream_of(boxes))
+        return d_boxes, d_sted, d_w, d_act, None, None
 
 
 # ------------------------------------------------------------------------------------

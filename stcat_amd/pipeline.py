@@ -91,23 +91,11 @@ class STCATNet(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
-# loss (API surface kept; stays PyTorch autograd on small tensors — SURVEY.md §2 #11)
+# loss: models/criterion.py's API surface over ONE HIP launch for all layers and terms (csrc/loss.h)
 # ------------------------------------------------------------------------------------------
 def box_cxcywh_to_xyxy(x):
     cx, cy, w, h = x.unbind(-1)
     return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
-
-
-def paired_giou(a, b):
-    """diag of generalized_box_iou (utils/box_utils.py:90-113) for matched xyxy boxes."""
-    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
-    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    wh = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)
-    inter = wh[:, 0] * wh[:, 1]
-    union = area_a + area_b - inter
-    wh_c = (torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)
-    hull = wh_c[:, 0] * wh_c[:, 1]
-    return inter / union - (hull - union) / hull
 
 
 class LossPlan:
@@ -145,11 +133,14 @@ class LossPlan:
         self.time_mask = time_mask.to(device)
         self.time_mask_f = time_mask.float().to(device)
         self.pos_or_pad = pos_or_pad.to(device)
-        self.nb_neg = ((~pos_or_pad).sum(1) + 1e-6).to(device)
-        self.act_weight = weight.to(device)
-        self.dist = torch.stack(dists, dim=-1).to(device)                       # [b,T,2]
-        self.tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).to(device)
-        self.actioness = torch.stack([t["actioness"] for t in targets]).float().to(device)
+        self.time_mask_u8 = time_mask.to(torch.uint8).to(device)
+        self.pos_or_pad_u8 = pos_or_pad.to(torch.uint8).to(device)
+        self.nb_neg = ((~pos_or_pad).sum(1) + 1e-6).float().to(device)
+        self.act_weight = weight.float().contiguous().to(device)
+        self.dist = torch.stack(dists, dim=-1).float().contiguous().to(device)  # [b,T,2]
+        self.tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).float().contiguous().to(device)
+        self.actioness = torch.stack([t["actioness"] for t in targets]).float().contiguous().to(device)
+        self.row_range = (rows[0], rows[-1] + 1) if rows == list(range(rows[0], rows[-1] + 1)) else None
 
     def num_boxes(self, dev):
         """criterion.py:175-178: box count averaged over ranks, clamped to >= 1.  It depends on the targets only,
@@ -166,8 +157,9 @@ class LossPlan:
 
 
 class VideoSTGLoss(nn.Module):
-    """Same constructor / forward contract as models/criterion.py:11-208.  All decoder layers (main + aux) are
-    evaluated in ONE vectorised pass over stacked [layers, ...] tensors instead of 6 x ~15 small ops."""
+    """Same constructor / forward contract as models/criterion.py:11-208.  All decoder layers (main + aux) and all
+    terms are evaluated by one kernel launch on the stacked [layers, ...] tensors (ops.StgLossFn), the gradient by one
+    more — the reference runs ~6 x 40 small tensor ops each way."""
 
     def __init__(self, cfg=None, losses: Sequence[str] = ("boxes", "sted", "guided_attn", "actioness"),
                  sigma: float = 2.0, eos_coef: float = 0.3):
@@ -175,9 +167,39 @@ class VideoSTGLoss(nn.Module):
         self.losses = list(losses)
         self.sigma = sigma if cfg is None else cfg.SOLVER.SIGMA
         self.eos_coef = eos_coef if cfg is None else cfg.SOLVER.EOS_COEF
+        self.weight_dict = None      # set (build_model does) to have the loss kernel also emit the weighted total
+        self._wmat_cache = None
+        self._last = None
 
     def plan(self, targets, durations, device) -> LossPlan:
         return LossPlan(targets, durations, device, self.sigma, self.eos_coef)
+
+    def _wmat(self, nl: int, dev):
+        """weight_dict laid out like the kernel's vec [5][nl] (row k = ops.LOSS_ROWS[k]; column nl-1 = the main output,
+        column i < nl-1 = aux output i, models/__init__.py:11-27)"""
+        wd = self.weight_dict
+        if wd is None:
+            return None
+        key = (id(wd), nl, str(dev))
+        if self._wmat_cache is None or self._wmat_cache[0] != key:
+            m = torch.zeros(5, nl)
+            keys = self._loss_keys()
+            for k, name in enumerate(ops.LOSS_ROWS):
+                if name not in keys:
+                    continue
+                for i in range(nl):
+                    m[k, i] = float(wd.get(name if i == nl - 1 else f"{name}_{i}", 0.0))
+            self._wmat_cache = (key, m.to(dev))
+        return self._wmat_cache[1]
+
+    def _loss_keys(self):
+        keys = []
+        if "boxes" in self.losses:
+            keys += ["loss_bbox", "loss_giou"]
+        for nm in ("sted", "guided_attn", "actioness"):
+            if nm in self.losses:
+                keys.append("loss_" + nm)
+        return keys
 
     def forward(self, outputs, targets, durations, plan: Optional[LossPlan] = None):
         dev = outputs["pred_boxes"].device
@@ -186,51 +208,43 @@ class VideoSTGLoss(nn.Module):
         aux = outputs.get("aux_outputs", [])
         layers = list(aux) + [outputs]                                              # main output last
         nl = len(layers)
-        # criterion.py:168-171 — the reference overwrites pred_boxes with the GT-span rows
         stk = outputs.get("_stacked")
         if stk is not None and stk["pred_boxes"].shape[0] != nl:
             stk = None                                                               # (aux losses disabled)
         _st = lambda key: stk[key] if stk is not None else torch.stack([l[key] for l in layers])  # noqa: E731
-        boxes = _st("pred_boxes")[:, plan.rows]                                     # [nl, nbox, 4]
-        for i, l in enumerate(layers):
-            l["pred_boxes"] = boxes[i]
-        num_boxes = plan.num_boxes(dev)
-        vec = {}
-        if "boxes" in self.losses:
-            tgt = plan.tgt_boxes[None].expand(nl, -1, -1)
-            vec["loss_bbox"] = (boxes - tgt).abs().sum((1, 2)) / num_boxes
-            giou = paired_giou(box_cxcywh_to_xyxy(boxes.reshape(-1, 4)), box_cxcywh_to_xyxy(tgt.reshape(-1, 4)))
-            vec["loss_giou"] = (1 - giou).view(nl, -1).sum(1) / num_boxes
-        if "sted" in self.losses:
-            sted = _st("pred_sted")                                                 # [nl,b,T,2]
-            sted = sted.masked_fill(~plan.time_mask[None, :, :, None], -1e32)
-            prob = sted.softmax(2)
-            kl = prob * ((prob + 1e-6) / plan.dist[None]).log() * plan.time_mask_f[None, :, :, None]
-            vec["loss_sted"] = kl.sum(3).mean((1, 2))
-        if "guided_attn" in self.losses:
-            w = _st("weights")                                                      # [nl,b,T,T]
-            la = (-(1 - w + 1e-6).log()).masked_fill(plan.pos_or_pad[None, :, :, None], 0)
-            vec["loss_guided_attn"] = (la.sum(3) / plan.nb_neg[None, :, None]).sum(2).mean(1)
+        coord = _st("pred_boxes")                                                   # [nl, rows, 4]
+        act = None
         if "actioness" in self.losses:
-            pa = _st("pred_actioness").squeeze(-1)                                  # [nl,b,T]
-            la = F.binary_cross_entropy_with_logits(pa, plan.actioness[None].expand(nl, -1, -1),
-                                                    weight=plan.act_weight[None].expand(nl, -1, -1), reduction="none")
-            vec["loss_actioness"] = (la * plan.time_mask_f[None]).mean((1, 2))
+            act = _st("pred_actioness").squeeze(-1)                                 # [nl,b,T]
+        # every term of every layer, one launch (csrc/loss.h); gradient: one more
+        vec, total = ops.StgLossFn.apply(coord, _st("pred_sted"), _st("weights"), act, plan, self._wmat(nl, dev))
+        # criterion.py:168-171 — the reference overwrites pred_boxes with the GT-span rows
+        for i, l in enumerate(layers):
+            l["pred_boxes"] = coord[i, plan.row_range[0]:plan.row_range[1]] if plan.row_range else coord[i][plan.rows]
         losses = {}
-        for k, v in vec.items():
-            losses[k] = v[nl - 1]
+        keys = self._loss_keys()
+        for k, name in enumerate(ops.LOSS_ROWS):
+            if name not in keys:
+                continue
+            losses[name] = vec[k, nl - 1]
             for i in range(nl - 1):
-                losses[f"{k}_{i}"] = v[i]
-        self._last_vec = vec
+                losses[f"{name}_{i}"] = vec[k, i]
+        self._last = (vec, total, nl)
         return losses
 
     def weighted_total(self, weight_dict):
-        """sum_k w_k * loss_k of the last forward, from the per-layer vectors (a handful of ops instead of 30)."""
-        total = 0
-        for k, v in self._last_vec.items():
-            if k in weight_dict:
-                total = total + weight_dict[k] * v.sum()
-        return total
+        """sum_k w_k * loss_k of the last forward.  With `self.weight_dict` set (build_model does) the kernel has already
+        summed it; any other weighting is applied to the per-layer vector here."""
+        vec, total, nl = self._last
+        if total is not None and (weight_dict is self.weight_dict or weight_dict == self.weight_dict):
+            return total
+        saved, self.weight_dict = self.weight_dict, weight_dict
+        try:
+            self._wmat_cache = None
+            m = self._wmat(nl, vec.device)
+        finally:
+            self.weight_dict, self._wmat_cache = saved, None
+        return (vec * m).sum()
 
 
 class PostProcess(nn.Module):
@@ -268,7 +282,9 @@ def weight_dict(cfg=None, n_dec: int = 6):
 
 def build_model(cfg=None, text_encoder=None):
     model = STCATNet(cfg, text_encoder)
-    return model, VideoSTGLoss(cfg), weight_dict(cfg)
+    criterion, wd = VideoSTGLoss(cfg), weight_dict(cfg)
+    criterion.weight_dict = wd
+    return model, criterion, wd
 
 
 def build_postprocessors():

@@ -765,3 +765,89 @@ def _gemm_bf16x6(dev, big):
     # three pieces per operand: fp32-class products
     with mma_mode("bf16x6", 2e-4):
         _gemm_family(dev, big)
+
+
+@both
+def _ew2d_strided(dev, big):
+    """row-strided two-operand entry: column blocks of wider matrices in, column block out"""
+    a, b = rnd(37, 96, seed=1), rnd(37, 64, seed=2)
+    ad, bd = a.to(dev), b.to(dev)
+    got = ops.ew2d(L.EW_MUL, ad[:, 32:64], bd[:, 16:48])
+    close(got, a[:, 32:64] * b[:, 16:48], 1e-6, "ew2d mul")
+    out = torch.zeros(37, 80, device=dev)
+    ops.ew2d(L.EW_ADD, ad[:, :32], bd[:, 32:], out=out[:, 48:])
+    close(out[:, 48:], a[:, :32] + b[:, 32:], 1e-6, "ew2d add into a column block")
+    assert float(out[:, :48].abs().max()) == 0.0
+    close(ops.ew2d(L.EW_COPY, ad[:, 5:69]), a[:, 5:69], 0.0, "ew2d copy")
+    a3 = rnd(3, 5, 48, seed=3)
+    close(ops.ew2d(L.EW_COPY, a3.to(dev)[..., 16:32]), a3[..., 16:32], 0.0, "ew2d copy 3-D")
+
+
+def _stg_loss_case(dev, T, nl, s, e, seed, with_act=True, world_nb=None):
+    """fused VideoSTGLoss kernel (values + gradients of every term and layer) vs the oracle's restatement of
+    models/criterion.py evaluated layer by layer in float64 autograd"""
+    from oracle import stcat_oracle as O
+    from stcat_amd.misc import BoxList
+    from stcat_amd.pipeline import VideoSTGLoss, weight_dict
+    g = torch.Generator().manual_seed(seed)
+    nbox = e - s + 1
+    boxes = torch.rand(nl, T, 4, generator=g) * 0.5 + 0.2
+    sted = torch.randn(nl, 1, T, 2, generator=g) * 2
+    w = torch.softmax(torch.randn(nl, 1, T, T, generator=g), dim=-1)
+    act = torch.randn(nl, 1, T, 1, generator=g)
+    tgt = torch.rand(nbox, 4, generator=g) * 0.4 + 0.3
+    actioness = torch.zeros(T, dtype=torch.bool)
+    actioness[s:e + 1] = True
+    wd = weight_dict(None, nl)
+    # ---- oracle, float64
+    ins64 = [t.double().requires_grad_(True) for t in (boxes, sted, w, act)]
+    out = {"pred_boxes": ins64[0][nl - 1], "pred_sted": ins64[1][nl - 1], "weights": ins64[2][nl - 1],
+           "pred_actioness": ins64[3][nl - 1],
+           "aux_outputs": [{"pred_boxes": ins64[0][i], "pred_sted": ins64[1][i], "weights": ins64[2][i],
+                            "pred_actioness": ins64[3][i]} for i in range(nl - 1)]}
+    ref = O.criterion(out, actioness, tgt.double())
+    if not with_act:
+        ref = {k: v for k, v in ref.items() if "actioness" not in k}
+    ref_total = sum(ref[k] * wd[k] for k in ref)
+    ref_total.backward(retain_graph=True)
+    # ---- HIP
+    ins = [t.to(dev).requires_grad_(True) for t in (boxes, sted, w, act)]
+    crit = VideoSTGLoss(None, losses=("boxes", "sted", "guided_attn") + (("actioness",) if with_act else ()))
+    crit.weight_dict = wd
+    outputs = {"pred_boxes": ins[0][nl - 1], "_stacked": {"pred_boxes": ins[0], "pred_sted": ins[1], "weights": ins[2],
+                                                          "pred_actioness": ins[3]},
+               "aux_outputs": [{} for _ in range(nl - 1)]}
+    targets = [{"actioness": actioness.to(dev), "boxs": BoxList(tgt, (64, 64)).to(dev)}]
+    losses = crit(outputs, targets, [T])
+    assert set(losses) == set(ref), (sorted(losses), sorted(ref))
+    for k in ref:
+        close(losses[k], ref[k].float(), 2e-5, f"loss {k}")
+    total = crit.weighted_total(wd)
+    close(total, ref_total.float(), 2e-5, "weighted total")
+    assert outputs["pred_boxes"].shape == (nbox, 4)           # criterion.py:168-171 side effect
+    total.backward()
+    for t, r, nm in zip(ins, ins64, ("boxes", "sted", "weights", "actioness")):
+        if nm == "actioness" and not with_act:
+            assert t.grad is None
+            continue
+        close(t.grad, r.grad.float(), 5e-5, f"d total / d {nm}")
+    # the per-term route (sum of selected losses with other weights) goes through gvec
+    for t in ins:
+        t.grad = None
+    losses = crit(outputs | {"pred_boxes": ins[0][nl - 1]}, targets, [T])
+    (losses["loss_giou"] * 2.0 + losses["loss_sted_0"] * 3.0).backward()
+    for r in ins64:
+        r.grad = None
+    (ref["loss_giou"] * 2.0 + ref["loss_sted_0"] * 3.0).backward()
+    close(ins[0].grad, ins64[0].grad.float(), 5e-5, "d giou / d boxes")
+    close(ins[1].grad, ins64[1].grad.float(), 5e-5, "d sted_0 / d sted")
+
+
+@both
+def _stg_loss(dev, big):
+    _stg_loss_case(dev, 8, 3, 2, 5, seed=1)
+    _stg_loss_case(dev, 5, 2, 0, 4, seed=2)                   # GT span = the whole clip: no negative rows
+    _stg_loss_case(dev, 7, 6, 3, 3, seed=3, with_act=False)   # one-frame span, actioness head off
+    if big:
+        _stg_loss_case(dev, 64, 6, 10, 50, seed=4)
+        _stg_loss_case(dev, 200, 6, 0, 120, seed=5)            # MAX_VIDEO_LEN

@@ -82,6 +82,19 @@ def main():
         a_[1] += e - s
     for k, (c, tns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print(f"    {tns/1e6:7.3f} ms {c:5d}x  {k}")
+    # library (at::native / rocPRIM) kernels by functor: what is still not ours
+    import re
+    lib = {}
+    for s, e, n in step:
+        if "at::native" in n or "rocprim" in n or "hipcub" in n:
+            m = re.search(r"(\w*Functor\w*|direct_copy_kernel\w*|CatArrayBatchedCopy\w*|reduce_kernel|\w*fill\w*|index\w*kernel\w*)", n)
+            k = (n.split("<")[0].split("::")[-1] + " / " + (m.group(1) if m else n[40:120]))
+            a_ = lib.setdefault(k, [0, 0])
+            a_[0] += 1
+            a_[1] += e - s
+    print(f"  library kernels: {sum(c for c, _ in lib.values())} launches, {sum(t for _, t in lib.values())/1e6:.3f} ms")
+    for k, (c, tns) in sorted(lib.items(), key=lambda kv: -kv[1][0])[:20]:
+        print(f"    {c:5d}x {tns/1e6:7.3f} ms  {k}")
 
 
 if __name__ == "__main__":
