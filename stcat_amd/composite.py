@@ -435,10 +435,17 @@ class BoxDecoderFn(Function):
         ctx.mem = (x_mem, x_pos, memory.shape)
         ctx.dims = (T, D, nl)
         ctx.refs = refs
-        return hs, ops.ew(L.EW_COPY, refs)       # (a copy: the node keeps `refs`, and an output held by its own node is a cycle)
+        # ---- box head on the normalised states of all layers (pipeline.py:88-93): same bbox_embed as the anchor update
+        e1, x_h1 = _lin_f(hs.view(nl * T, D), Wb1, bb1, relu=True)
+        e2, x_h2 = _lin_f(e1, Wb2, bb2, relu=True)
+        tmp, x_h3 = _lin_f(e2, Wb3, bb3)
+        coord = ops.ew(L.EW_SIGMOID, ops.ew(L.EW_ADD, tmp, ops.ew(L.EW_INVSIG, refs.view(nl * T, 4))))
+        ctx.head = (x_h1, x_h2, x_h3, e1, e2, coord)
+        # (copies: the node keeps `refs` / `coord`, and an output held by its own node is a reference cycle)
+        return hs, ops.ew(L.EW_COPY, refs), ops.ew(L.EW_COPY, coord).view(nl, T, 4)
 
     @staticmethod
-    def backward(ctx, d_hs, d_refs):
+    def backward(ctx, d_hs, d_refs, d_coord):
         T, D, nl = ctx.dims
         prm, refs = ctx.prm, ctx.refs
         x_mem, x_pos, mshape = ctx.mem
@@ -453,6 +460,15 @@ class BoxDecoderFn(Function):
         d_hs = d_hs if d_hs.is_contiguous() else d_hs.contiguous()
         if d_refs is not None and not d_refs.is_contiguous():
             d_refs = d_refs.contiguous()
+        if d_coord is not None:                          # box head
+            x_h1, x_h2, x_h3, e1, e2, coord = ctx.head
+            d_pre = ops.ew(L.EW_SIGMOID_BWD, d_coord.contiguous().view(nl * T, 4), coord)
+            d_r = ops.ew(L.EW_INVSIG_BWD, d_pre, refs.view(nl * T, 4)).view(nl, T, 4)
+            d_refs = d_r if d_refs is None else _add(d_refs, d_r)
+            d_e2, _, _, _ = _lin_b(d_pre, x_h3, Wb3, dw=dWb3, db=dbb3)
+            d_e1, _, _, _ = _lin_b(d_e2, x_h2, Wb2, dw=dWb2, db=dbb2, relu_y=e2)
+            d_hs, _, _, _ = _lin_b(d_e1, x_h1, Wb1, dw=dWb1, db=dbb1, relu_y=e1, add=d_hs.view(nl * T, D))
+            d_hs = d_hs.view(nl, T, D)
         d_layers = [None] * nl
         d_anchor = None
         d_next = None                                  # gradient reaching layer i's output state from layer i+1
@@ -655,3 +671,61 @@ def encoder(enc, vis_tokens, txt, vis_pos, kpm_full, tpos):
                     l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias)
     return EncoderFn.apply(vis_tokens, txt, vis_pos, kpm_full, tpos, p, enc.spatial_layers[0].nhead, enc.num_layers,
                            enc.frame_cls.weight, enc.local_pos_embed.weight, enc.video_cls.weight, *prm)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# span / actioness heads on the time decoder's states (pipeline.py:98-103): two MLPs with dropout, one node
+# ------------------------------------------------------------------------------------------------------------------
+class TimeHeadsFn(Function):
+    """time_hs [L,T,D] -> (sted [L,T,2], act [L,T,1] | None); MLP = Linear-ReLU-dropout-Linear-dropout
+    (net_utils.py:7-26 applies the dropout after every layer)"""
+
+    @staticmethod
+    def forward(ctx, time_hs, p, Wt1, bt1, Wt2, bt2, Wa1, ba1, Wa2, ba2):
+        shp = time_hs.shape
+        x = time_hs.contiguous().view(-1, shp[-1])
+        st = []
+        outs = []
+        for (W1, b1, W2, b2) in ((Wt1, bt1, Wt2, bt2), (Wa1, ba1, Wa2, ba2)):
+            if W1 is None:
+                outs.append(None)
+                st.append(None)
+                continue
+            h, x1 = _lin_f(x, W1, b1, relu=True)
+            hd, c1 = (_f(ops.DropoutFn, _T, h, None, p) if p > 0.0 else (h, None))
+            y, x2 = _lin_f(hd, W2, b2)
+            yd, c2 = (_f(ops.DropoutFn, _T, y, None, p) if p > 0.0 else (y, None))
+            outs.append(yd.view(*shp[:-1], W2.shape[0]))
+            st.append((x1, h, c1, x2, c2, W1, W2))
+        ctx.st = st
+        ctx.shp = shp
+        ctx.set_materialize_grads(False)
+        if outs[1] is None:
+            ctx.mark_non_differentiable()
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, d_sted, d_act):
+        d_x = None
+        grads = []
+        for g, st in zip((d_sted, d_act), ctx.st):
+            if st is None or g is None:
+                grads += [None] * 4
+                continue
+            x1, h, c1, x2, c2, W1, W2 = st
+            g = g.contiguous().view(-1, W2.shape[0])
+            if c2 is not None:
+                g = ops.DropoutFn.backward(c2, g)[0]
+            d_hd, dW2, db2, _ = _lin_b(g, x2, W2)
+            if c1 is not None:
+                d_hd = ops.DropoutFn.backward(c1, d_hd.view(h.shape))[0]
+            d_x, dW1, db1, _ = _lin_b(d_hd, x1, W1, relu_y=h, add=d_x)
+            grads += [dW1, db1, dW2, db2]
+        return (d_x.view(ctx.shp) if d_x is not None else None, None) + tuple(grads)
+
+
+def time_heads(temp_embed, action_embed, time_hs):
+    p = temp_embed.dropout_p if temp_embed.training else 0.0
+    wb = lambda m: (m.weight, m.bias)       # noqa: E731
+    a = (wb(action_embed.layers[0]) + wb(action_embed.layers[1])) if action_embed is not None else (None,) * 4
+    return TimeHeadsFn.apply(time_hs, p, *(wb(temp_embed.layers[0]) + wb(temp_embed.layers[1])), *a)

@@ -458,7 +458,9 @@ class QueryDecoder(nn.Module):
                 mem_plus_pos = ops.add_const(memory, mem_pos)                                # memory + pos  :636
                 time_hs, weights = self.temp_decoder.run(memory, mem_plus_pos, mem_kpm, temp_query.contiguous(),
                                                          time_embed)
-        hs, ref = self.decoder.run(memory, mem_kpm, mem_pos, anchor, time_embed)
+        dec_out = self.decoder.run(memory, mem_kpm, mem_pos, anchor, time_embed)
+        hs, ref = dec_out[0], dec_out[1]
+        self.last_coord = dec_out[2] if len(dec_out) > 2 else None    # the box head, evaluated inside the decoder node
         fork.join(time_hs, weights)
         return hs, ref, time_hs, weights, pos_query
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import composite, ops
 from .backbone import build_vis_encoder
 from .grounding import MLP, build_decoder, build_encoder
 from .misc import NestedTensor
@@ -69,13 +69,21 @@ class STCATNet(nn.Module):
         hs, ref, time_hs, weights, _ = self.ground_decoder.run(memory.contiguous(), mem_mask, mem_pos,
                                                                frames_cls, video_cls)       # :77-80
         out = {"weights": weights[-1]}                                                       # :83-85
-        coord = ops.sigmoid(ops.add(self.bbox_embed(hs), ops.inverse_sigmoid(ref)))          # [L,T,4]  :88-93
+        coord, self.ground_decoder.last_coord = getattr(self.ground_decoder, "last_coord", None), None
+        if coord is None:
+            coord = ops.sigmoid(ops.add(self.bbox_embed(hs), ops.inverse_sigmoid(ref)))      # [L,T,4]  :88-93
         out["pred_boxes"] = coord[-1]
-        sted = self.temp_embed(time_hs)[:, None]                                             # [L,1,T,2]  :98
-        out["pred_sted"] = sted[-1]
         act = None
-        if self.use_actioness:
-            act = self.action_embed(time_hs)[:, None]                                        # :103
+        if composite.ENABLED:
+            sted, act = composite.time_heads(self.temp_embed, self.action_embed if self.use_actioness else None, time_hs)
+            sted = sted[:, None]                                                             # [L,1,T,2]  :98
+            act = act[:, None] if act is not None else None                                  # :103
+        else:
+            sted = self.temp_embed(time_hs)[:, None]
+            if self.use_actioness:
+                act = self.action_embed(time_hs)[:, None]
+        out["pred_sted"] = sted[-1]
+        if act is not None:
             out["pred_actioness"] = act[-1]
         # the per-layer tensors, still stacked [layers, ...]: VideoSTGLoss evaluates all layers in one vectorised pass
         # and would otherwise re-stack what the loop below unstacks (and pay ~70 select-backward/add launches)
