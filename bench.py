@@ -128,6 +128,18 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+def _shape_key(name, a):
+    """conv shape of a plane-GEMM launch, for the per-shape table of the instrumented step"""
+    if name in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad", "stcat_pl_conv_wgrad"):
+        o = {"stcat_pl_conv_fwd": 12, "stcat_pl_conv_dgrad": 15, "stcat_pl_conv_wgrad": 6}[name]
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[o:o + 9]
+        return f"{name[9:]} {n}x{H}x{W} {Cin}->{Cout} k{KH} s{stride}"
+    if name in ("stcat_linear_fwd", "stcat_linear_dgrad", "stcat_linear_wgrad"):
+        o = {"stcat_linear_fwd": 5, "stcat_linear_dgrad": 5, "stcat_linear_wgrad": 4}[name]
+        return f"{name[6:]} M{a[o]} N{a[o + 1]} K{a[o + 2]}"
+    return None
+
+
 class LaunchProfiler:
     """Wraps _lib.call with a pair of HIP events per launch (same stream as the launch)."""
 
@@ -143,7 +155,7 @@ class LaunchProfiler:
             e0.record()
             self._orig(name, *args)
             e1.record()
-            self.records.append((name, _flops(name, args), e0, e1))
+            self.records.append((name, _flops(name, args), e0, e1, _shape_key(name, args)))
 
         _lib.call = timed
         import stcat_amd.ops as ops_mod
@@ -156,12 +168,25 @@ class LaunchProfiler:
 
     def summary(self):
         agg = {}
-        for name, fl, e0, e1 in self.records:
+        self.shapes = {}
+        for name, fl, e0, e1, key in self.records:
+            ms = e0.elapsed_time(e1)
             d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += ms
             d["flop"] += fl
+            if key:
+                d = self.shapes.setdefault(key, {"launches": 0, "ms": 0.0, "flop": 0.0})
+                d["launches"] += 1
+                d["ms"] += ms
+                d["flop"] += fl
         return agg
+
+    def shape_table(self, top=24):
+        """the heaviest GEMM shapes of the instrumented step: launches, total ms, algorithmic TFLOP/s"""
+        rows = sorted(self.shapes.items(), key=lambda kv: -kv[1]["ms"])[:top]
+        return {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flop"] / v["ms"] / 1e9, 1)}
+                for k, v in rows if v["ms"] > 0}
 
 
 def cpu_baseline(T_sample: int, res: int, L: int, T_full: int, threads: int, reps: int = 3):
@@ -328,9 +353,12 @@ def main():
     fence()
     comm_events.clear()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     for _ in range(args.steps):
         step()
     host_s = time.perf_counter() - t0  # host time to ENQUEUE the steps (no sync): ~= elapsed means launch-bound
+    host_cpu_s = time.process_time() - c0  # CPU time of all threads of this process while enqueuing (python + autograd
+    #                                        engine thread + HIP runtime): excludes the time a full launch queue blocks
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
     if comm:
@@ -343,7 +371,7 @@ def main():
     if graphed is not None:  # the instrumented / side measurements below time individual launches: eager mode
         reducer.defer(False)
         step = eager_step
-    roof, kernels = None, None
+    roof, kernels, gemm_shapes = None, None, None
     if not args.no_profile:
         # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events
         if rank == 0:
@@ -389,6 +417,7 @@ def main():
         mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)
         roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
                                     "gflop_per_step": round(mm / 1e9, 1)}
+        gemm_shapes = prof.shape_table()
     if comm:
         dist.barrier()
 
@@ -507,6 +536,7 @@ def main():
             "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
+            "host_cpu_ms_per_step": round(1e3 * host_cpu_s / args.steps, 2),
             "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
@@ -525,6 +555,7 @@ def main():
                             "(criterion.py:175-178) are built once per batch OUTSIDE the timed step (they depend on "
                             "the annotations only; the reference rebuilds them inside its loss every step)",
             "kernels": kernels,
+            "gemm_shapes": gemm_shapes,
         }
     # The JSON line must be the LAST thing on stdout.  RCCL writes a version banner through C stdio, which is
     # block-buffered when stdout is a pipe and would otherwise be flushed at process exit, AFTER the line: flush
