@@ -316,8 +316,14 @@ struct PlTile { int bm, bn; float eff; };
 const PlTile kPlTiles[6] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f},
                             {224, 256, 1.04f}};
 
-int pick_pl_tile(int M, int N) {
+int pick_pl_tile(int M, int N, int K) {
   if (g_pl_force >= 0 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
+  // Short reductions (K <= 512: the 1x1 expand / reduce convs and their data gradients) and N = 128 are bound by the
+  // epilogue's HBM traffic (residual / mask in, planes out), not by the matrix pipe.  The 128 x 128 tile needs 64 KB of
+  // LDS, so TWO workgroups share a CU and one's epilogue overlaps the other's loads: measured with step-like operands
+  // (tools/bench_gemm.py --step-like, profiles/r02_plane_gemm_steplike.log) 0.220 -> 0.186 ms (256 -> 1024 forward),
+  // 0.251 -> 0.204 ms (1024 -> 256 data gradient), 0.583 -> 0.472 ms (layer1 64 -> 256).
+  if (N % 128 == 0 && (K <= 512 || N == 128) && (long)M * N >= (1l << 22)) return 3;
   int best = -1;
   float best_cost = 0.f;
   for (int i = 0; i < 6; ++i) {
@@ -337,7 +343,7 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
-  const int ti = pick_pl_tile(p.M, p.N);
+  const int ti = pick_pl_tile(p.M, p.N, p.K);
   if (ti < 0) return fail("plane GEMM: N = %d is not a multiple of 64", p.N);
   const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
   const dim3 grid(cdiv(p.M, BM) * (p.N / BN));

@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--pl-tile", type=int, default=-1, help="force the plane-GEMM tile index (bf16x3p)")
     ap.add_argument("--pl-flags", type=int, default=0, help="stcat_debug_pl_flags (timing experiments)")
+    ap.add_argument("--step-like", action="store_true", help="bf16x3p: operands as in the training step — the forward "
+                    "reads a residual, the data gradient an `add` operand, and launches rotate over operand sets larger "
+                    "than the 256 MB Infinity Cache (a step never finds its operands cached)")
     args = ap.parse_args()
     L.load(os.environ.get("STCAT_LIB_OVERRIDE", L.LIB_PATH))  # experiment builds only
     L.set_mma_mode(args.mma)
@@ -79,19 +82,44 @@ def main():
             wp, wt = cache.refresh([w], transposed=True)
             wp, wt = wp[w.data_ptr()], wt[w.data_ptr()]
             yp, _ = ops.pl_conv_fwd_raw(xp, wp, sc, bi, None, stride, pad, True)
-            gp = ops.pl_split(torch.randn(*yp.shape, device=dev))
             flop = 2.0 * yp.numel() * k * k * Cin
-            dxo = ops.Planes.empty(x, *x.shape)
-            t_f = timeit(lambda: ops.pl_conv_fwd_raw(xp, wp, sc, bi, None, stride, pad, True))
-            t_d = timeit(lambda: ops.pl_conv_dgrad_raw(gp, wt, x.shape, k, stride, pad, out=dxo, mask_y=xp, mask_scale=None))
+            R = 3 if args.step_like else 1
+            sets = []
+            for r in range(R):
+                st = {"xp": ops.pl_split(torch.randn(n, H, W, Cin, device=dev)) if r else xp,
+                      "gp": ops.pl_split(torch.randn(*yp.shape, device=dev)),
+                      "dxo": ops.Planes.empty(x, *x.shape), "res": None, "add": None}
+                if args.step_like:
+                    st["res"] = ops.pl_split(torch.randn(*yp.shape, device=dev))
+                    st["add"] = ops.pl_split(torch.randn(*x.shape, device=dev))
+                sets.append(st)
+            it = [0]
+
+            def nxt():
+                it[0] += 1
+                return sets[it[0] % R]
+
+            def f_fwd():
+                s_ = nxt()
+                ops.pl_conv_fwd_raw(s_["xp"], wp, sc, bi, s_["res"], stride, pad, True)
+
+            def f_dgrad():
+                s_ = nxt()
+                ops.pl_conv_dgrad_raw(s_["gp"], wt, x.shape, k, stride, pad, add=s_["add"], out=s_["dxo"], mask_y=s_["xp"],
+                                      mask_scale=None)
+            t_f = timeit(f_fwd, iters=12)
+            t_d = timeit(f_dgrad, iters=12)
             t_w = float("nan")
             if Cin % 128 == 0 and Cout % 128 == 0:
                 dw = torch.zeros_like(w)
 
                 def wgp():
-                    L.call("stcat_pl_conv_wgrad", gp.h, gp.l, xp.h, xp.l, dw.data_ptr(), None, n, H, W, Cin, Cout, k, k, stride,
-                           pad, L.stream_of(x))
-                t_w = timeit(wgp)
+                    s_ = nxt()
+                    L.call("stcat_pl_conv_wgrad", s_["gp"].h, s_["gp"].l, s_["xp"].h, s_["xp"].l, dw.data_ptr(), None, n, H, W,
+                           Cin, Cout, k, k, stride, pad, L.stream_of(x))
+                t_w = timeit(wgp, iters=12)
+            gp = dxo = None
+            del sets
             for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
                 if t == t:
                     tot[key][0] += flop
