@@ -249,6 +249,8 @@ class _BackboneFnPl(Function):
         # chip unevenly (layer3: 196-224 workgroups on 256 CUs, a partial last round elsewhere): the weight-gradient
         # workgroups run on the CUs the data-gradient launch leaves idle.
         wg = ops.WgradStream(dy)
+        sink = ops.GRAD_SINK
+        delivered = set()
 
         def wgrad(key, g, xin, wshape, stride, pad, row_scale=None):
             with wg:
@@ -270,6 +272,15 @@ class _BackboneFnPl(Function):
             wgrad(id(blk.conv1.weight), g1, x, w1.shape, 1, 0)
             if wd is not None:
                 wgrad(id(blk.downsample[0].weight), dz, x, wd.shape, blk.stride, 0, sd)
+            if sink is not None:
+                # data-parallel run: this block's weight gradients go to the gradient exchange now, from the weight-
+                # gradient stream (behind the kernels that write them), not at the end of the whole backbone backward
+                ws = [blk.conv3.weight, blk.conv2.weight, blk.conv1.weight]
+                if wd is not None:
+                    ws.append(blk.downsample[0].weight)
+                with wg:
+                    if sink.early(ws, [grads[id(w_)].permute(0, 3, 1, 2) for w_ in ws]):
+                        delivered.update(id(w_) for w_ in ws)
             if not need_dx:
                 break
             # block boundary: x is the ReLU output of the block below; its dz comes out of this epilogue
@@ -281,7 +292,7 @@ class _BackboneFnPl(Function):
         wg.join(*grads.values())
         out = []
         for w in ctx.plist:
-            g = grads.get(id(w))
+            g = grads.get(id(w)) if id(w) not in delivered else None
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)
         ctx.tape = None
         ctx.wt = None

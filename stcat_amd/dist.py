@@ -10,6 +10,11 @@ the reference model in torch DDP with find_unused_parameters=True).  Here instea
   by a graph walk every step;
 * when the last gradient of a bucket has been accumulated its all-reduce is launched asynchronously —
   RCCL runs it on its own stream while the (much longer) backbone backward keeps the compute stream busy;
+* the backbone is ONE autograd node (its backward is ~27 of the step's ~62 ms), so autograd would hand over all of
+  its gradients at the very end: the node instead delivers them block by block through ``early()`` (registered as
+  ``ops.GRAD_SINK``) from its weight-gradient stream, and the buckets are laid out so that the LAST one to complete
+  (layer2 + the tail of layer3) is small — what remains exposed after the last kernel of backward is one <= 16 MB
+  all-reduce instead of a 128 MB one;
 * ``finish()`` waits for the collectives and applies the 1/world mean.
 
 xGMI is point-to-point (7 links per GPU): few large messages beat many small ones, hence big buckets.
@@ -31,8 +36,8 @@ def live_trainable(named_params):
 
 
 class GradBucketReducer:
-    def __init__(self, model: torch.nn.Module, bucket_mb: float = 128.0, process_group=None, extra_numel: int = 0,
-                 force_comm: bool = False):
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 64.0, process_group=None, extra_numel: int = 0,
+                 force_comm: bool = False, tail_mb: float = 16.0):
         """extra_numel: a dummy tail bucket (e.g. 124.6 M elements to emulate the reference's RoBERTa gradients
         in the message size) — reduced with the rest, never read."""
         self.group = process_group
@@ -60,6 +65,19 @@ class GradBucketReducer:
             cur_n += p.numel()
         if cur:
             self.buckets.append({"params": cur, "numel": cur_n, "late": False})
+        # small LAST bucket: whatever completes last is fully exposed, so cut the tail of the readiness order off
+        tail_cap = int(tail_mb * (1 << 20) // 4)
+        if self.buckets and self.buckets[-1]["numel"] > tail_cap and len(self.buckets[-1]["params"]) > 1:
+            lastb = self.buckets.pop()
+            tail, tail_n = [], 0
+            head = list(lastb["params"])
+            while len(head) > 1 and tail_n + head[-1][1].numel() <= tail_cap:
+                n_, p_ = head.pop()
+                tail.insert(0, (n_, p_))
+                tail_n += p_.numel()
+            self.buckets.append({"params": head, "numel": sum(p_.numel() for _, p_ in head), "late": False})
+            if tail:
+                self.buckets.append({"params": tail, "numel": tail_n, "late": False})
         if late:
             self.buckets.append({"params": late, "numel": sum(p.numel() for _, p in late), "late": True})
         self._owner = {}
@@ -85,6 +103,14 @@ class GradBucketReducer:
         self._extra_work = None
         self.extra_numel = extra_numel
         self.deferred = False  # True: hooks do nothing, finish() reduces the (static) gradient tensors afterwards
+        self._view_of = {}
+        for b in self.buckets:
+            for (n, p), v in zip(b["params"], b["views"]):
+                self._view_of[p] = v
+        self._early = set()
+        if self.comm:
+            from . import ops
+            ops.GRAD_SINK = self   # nodes that produce many parameter gradients hand them over as they complete
         self.no_overlap = bool(os.environ.get("STCAT_REDUCER_NO_OVERLAP"))  # diagnostic: all buckets in finish()
 
     # ---- per step -------------------------------------------------------------------------------
@@ -93,9 +119,40 @@ class GradBucketReducer:
         per parameter; buckets are gathered with one fused multi-tensor copy when they complete."""
         for p in self.params:
             p.grad = None
+        self._early.clear()
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+
+    def close(self):
+        from . import ops
+        if ops.GRAD_SINK is self:
+            ops.GRAD_SINK = None
+
+    def early(self, params, grads) -> bool:
+        """Called from INSIDE a backward node, on the stream that produced `grads`: take these parameter gradients
+        now (the node then returns None for them, so no AccumulateGrad / hook runs later).  Copies run on the current
+        stream, i.e. behind the kernels that wrote the gradients; a bucket that completes is reduced right away."""
+        if not self.comm or self.deferred:
+            return False
+        touched = []
+        srcs, dsts = [], []
+        for p, g in zip(params, grads):
+            if p not in self._view_of:
+                return False          # (a parameter outside the buckets: let autograd handle the whole group)
+        for p, g in zip(params, grads):
+            srcs.append(g)
+            dsts.append(self._view_of[p])
+            self._early.add(p)
+            b = self.buckets[self._owner[p]]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                touched.append(b)
+        torch._foreach_copy_(dsts, srcs)
+        for b in touched:
+            if not b["late"] and not self.no_overlap:
+                self._launch(b)
+        return True
 
     def defer(self, on: bool = True):
         """Deferred mode for a hipGraph-captured step (stcat_amd/graph.py): gradient hooks launch nothing (a
@@ -115,7 +172,9 @@ class GradBucketReducer:
         if self.comm:
             srcs, dsts = [], []
             grads = b.get("static") if self.deferred else [p.grad for _, p in b["params"]]
-            for g, v in zip(grads, b["views"]):
+            for (n, p), g, v in zip(b["params"], grads, b["views"]):
+                if p in self._early:
+                    continue              # delivered through early(): already in the flat buffer
                 if g is not None:
                     srcs.append(g)
                     dsts.append(v)

@@ -101,6 +101,7 @@ def dim_t(device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------
 _SIDE_STREAMS = {}
 FORK_ENABLED = not os.environ.get("STCAT_NO_FORK")  # two-stream decoders (QueryDecoder.run)
+GRAD_SINK = None  # dist.GradBucketReducer when gradients are exchanged: .early(params, grads) takes them mid-backward
 
 
 class fork_stream:
@@ -109,12 +110,9 @@ class fork_stream:
     outputs are used on the current stream from now on.  A no-op on the emulator backend / when disabled."""
 
     def __init__(self, like: torch.Tensor):
-        # Measured at C3 (bench.py): single GPU 84.1 -> 82.1 ms with the fork; with the gradient exchange active
-        # (STCAT_FORCE_COMM=1: RCCL stream + bucket copies) 84.7 -> 87.0 ms — so it is used only when this process
-        # is not part of a process group (STCAT_FORK=1 forces it).
-        import torch.distributed as dist
-        on = FORK_ENABLED and (not (dist.is_available() and dist.is_initialized()) or bool(os.environ.get("STCAT_FORK")))
-        self.active = on and L._backend == "hip" and like.is_cuda
+        # Measured at C3 (bench.py, round 2): single GPU 65.2 -> 62.8 ms with the fork; with the gradient exchange active
+        # (STCAT_FORCE_COMM=1: RCCL stream + bucket copies) 70.3 -> 66.3 ms — N = 1 and N > 1 run the same schedule.
+        self.active = FORK_ENABLED and L._backend == "hip" and like.is_cuda
         if self.active:
             dev = like.device
             self.main = torch.cuda.current_stream(dev)

@@ -103,3 +103,87 @@ def test_reducer_single_process_is_identity():
     ref(torch.ones(1, 8, 5, 5)).sum().backward()
     for (n, p), (_, q) in zip(live_trainable(model.named_parameters()), live_trainable(ref.named_parameters())):
         assert torch.allclose(p.grad, q.grad), n
+
+
+# ---- early delivery: a backward node hands parameter gradients to the reducer itself (ops.GRAD_SINK) -----------------
+class _EarlyConv(torch.autograd.Function):
+    """conv whose backward delivers dW through the gradient sink and returns None for it — what the backbone node does
+    block by block (stcat_amd/backbone.py)"""
+
+    @staticmethod
+    def forward(ctx, x, w, owner):
+        ctx.save_for_backward(x)
+        ctx.owner = owner
+        return torch.nn.functional.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        from stcat_amd import ops
+        (x,) = ctx.saved_tensors
+        w = ctx.owner.conv.weight
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, g)
+        took = ops.GRAD_SINK is not None and ops.GRAD_SINK.early([w], [dw])
+        ctx.owner.took.append(bool(took))
+        return None, (None if took else dw), None
+
+
+class ToyEarly(Toy):
+    def __init__(self):
+        super().__init__()
+        self.took = []
+
+    def forward(self, x):
+        return self.lin(_EarlyConv.apply(x, self.conv.weight, self).mean((2, 3)))
+
+
+def _worker_early(rank, world, port, q):
+    from stcat_amd import ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = ToyEarly()
+    red = GradBucketReducer(model, bucket_mb=0.002)
+    assert ops.GRAD_SINK is red
+    res = []
+    for step in range(2):
+        red.zero_grad()
+        x = torch.full((2, 8, 5, 5), float(rank + 1 + step))
+        model(x).square().sum().backward()
+        red.finish()
+        res.append({n: p.grad.clone().numpy() for n, p in live_trainable(model.named_parameters())})
+    assert model.took == [True, True]
+    red.close()
+    assert ops.GRAD_SINK is None
+    q.put((rank, res, red.message_bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_early_delivery_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_early, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(2):
+        want = _single(step)
+        for rank, res, nbytes in out:
+            for n, g in res[step].items():
+                assert torch.allclose(torch.from_numpy(g), want[n], rtol=1e-5, atol=1e-6), (rank, step, n)
+
+
+def test_bucket_layout_has_a_small_tail():
+    """readiness-ordered buckets of at most bucket_mb with a last bucket of at most tail_mb (what completes last is the
+    exposed part of the exchange)"""
+    m = nn.Sequential(*[nn.Linear(64, 64, bias=False) for _ in range(10)])   # 10 x 16 KB, registered first = ready last
+    red = GradBucketReducer(m, bucket_mb=0.0625, tail_mb=0.02)                # 64 KB buckets, 20 KB tail
+    sizes = [b["numel"] * 4 for b in red.buckets]
+    assert sum(sizes) == 10 * 64 * 64 * 4
+    assert sizes[-1] <= 20 * 1024 and max(sizes) <= 64 * 1024
+    assert [n for n, _ in red.buckets[-1]["params"]] == ["0.weight"]          # the first layer's gradient is ready last

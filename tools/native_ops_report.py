@@ -10,13 +10,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from backends import use_emu  # noqa: E402
+from backends import use_emu, use_hip  # noqa: E402
 from stcat_amd import ops, synth  # noqa: E402
 from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
 from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
 
-dev = use_emu()
-T, res, L = 2, 64, 3
+HIP = "--hip" in sys.argv          # on the GPU box: the real library, config C1, zero arena on (as bench.py runs)
+dev = use_hip() if HIP else use_emu()
+T, res, L = (8, 224, 10) if HIP else (2, 64, 3)
 model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
 synth.fill_module_(model)
 model.to(dev).train()
@@ -26,11 +27,14 @@ act, tb = synth.synth_targets(T)
 targets = [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}]
 plan = criterion.plan(targets, [T], dev)
 plan.num_boxes(dev)
+arena = ops.enable_zero_arena(dev, 120_000_000) if HIP else None
 
 
 def step():
     for p in model.parameters():
         p.grad = None
+    if arena is not None:
+        arena.reset()
     out = model(videos, ["synthetic"])
     criterion(out, targets, [T], plan=plan)
     total = criterion.weighted_total(wd)
@@ -52,7 +56,7 @@ class Rec(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
         short = name.replace("aten.", "")
-        if not any(short.startswith(v) for v in VIEW) and not (short.startswith("zero_") or short.startswith("zeros")):
+        if not any(short.startswith(v) for v in VIEW) and (HIP or not (short.startswith("zero_") or short.startswith("zeros"))):
             where = "autograd engine (no stcat_amd frame)"
             for fr in reversed(traceback.extract_stack()):
                 if "stcat_amd/" in fr.filename:
