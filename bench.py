@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=list(synth.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
     ap.add_argument("--cpu-sample-frames", type=int, default=8,
                     help="frames of the bounded CPU-baseline sample (1 warm-up + 3 repetitions are timed)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
@@ -257,6 +258,8 @@ def main():
     local = min(local, torch.cuda.device_count() - 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # one process per GPU, on the CPUs of the socket that GPU hangs off (two-socket hosts, four GPUs per socket)
+    host_cpus = None if args.no_pin else _lib.pin_host_threads_to_gpu(local)
     # STCAT_FORCE_COMM=1: run the complete RCCL path (process group, barriers, bucketed async all-reduce, the
     # loss's box-count all-reduce) even with ONE rank — the only way to exercise it on a 1-GPU box
     force_comm = bool(os.environ.get("STCAT_FORCE_COMM")) and world == 1
@@ -537,6 +540,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
             "host_cpu_ms_per_step": round(1e3 * host_cpu_s / args.steps, 2),
+            "host_cpus": host_cpus,
             "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",

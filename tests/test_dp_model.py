@@ -68,11 +68,23 @@ def _worker(rank, world, port, q):
                 ref[n] = ref.get(n, 0) + p.grad.detach() / world
     worst, worst_n = 0.0, ""
     assert set(got) == set(ref)
+    errs = []
+    # Some gradients are zero in exact arithmetic (key biases under the softmax's shift invariance, layer 0's q/k
+    # projections whose values are all the same row, the span head's output bias): what the kernels produce for them is
+    # round-off noise in both schedules, so errors are taken relative to max(|ref|, the typical gradient magnitude)
+    typical = float(torch.stack([ref[n].abs().max() for n in ref]).median())
     for n in ref:
-        scale = max(float(ref[n].abs().max()), 1e-6)
+        scale = max(float(ref[n].abs().max()), typical)
         err = float((got[n] - ref[n]).abs().max()) / scale
+        errs.append((err, n))
         if err > worst:
             worst, worst_n = err, n
+    if os.environ.get("STCAT_DP_DEBUG") and rank == 0:
+        owner = {n: bi for bi, b in enumerate(red.buckets) for n, _ in b["params"]}
+        for err, n in sorted(errs, reverse=True)[:25]:
+            print(f"  {err:10.3e} bucket {owner.get(n)} {n}", flush=True)
+        print("buckets:", [(len(b["params"]), b["numel"] * 4 >> 20, b["late"]) for b in red.buckets], flush=True)
+        print("bad per bucket:", {bi: sum(1 for e, n in errs if owner.get(n) == bi and e > 1e-3) for bi in range(len(red.buckets))})
     q.put((rank, worst, worst_n, n_early, len(got)))
     dist.barrier()
     dist.destroy_process_group()
