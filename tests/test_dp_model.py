@@ -107,5 +107,7 @@ def test_two_rank_gradients_equal_single_process_mean_c1():
     for rank, worst, name, n_early, n_grads in out:
         assert n_early >= 90, n_early                 # the backbone's conv weights went through early()
         assert n_grads > 500
-        # weight gradients are split-K sums added atomically in arrival order: fp32 round-off, not bitwise
-        assert worst < 2e-4, (rank, worst, name)
+        # Not bitwise: weight gradients are split-K sums added atomically in arrival order, and a round-off-sized change
+        # of a pre-activation flips a ReLU mask bit here and there (measured run-to-run: 2e-4 in the backbone, up to
+        # 1.6e-3 on the encoder's FFN).  A missing or doubled rank contribution would be an O(1) error.
+        assert worst < 5e-3, (rank, worst, name)
