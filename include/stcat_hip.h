@@ -154,6 +154,14 @@ int stcat_linear_fwd(const float* x, const float* w, const float* bias, const fl
 /* dx[M,K] = g[M,N] . w[N,K] (+ add[M,K]);  K % 64 == 0, N % 16 == 0; wt = optional w^T [K][N] (weight_transpose) */
 int stcat_linear_dgrad(const float* g, const float* w, const float* add, const float* wt, float* dx, int M, int N,
                        int K, int ldg, int lddx, void* stream);
+/* Accumulating forms for the decoders' skinny launches (M <= 128; the [T,256] query states, query_decoder.py:329-438,
+ * 587-660): y += x w^T + bias (+ res) and dx += g w (+ add) onto outputs that already hold the value to add to (zeros
+ * from the caller's zeroed arena).  The reduction is split over grid.z (>= 2 K-tiles per slice, atomic epilogue) with
+ * no memset launch in front.  Split-bf16 modes only; other shapes are refused. */
+int stcat_linear_fwd_acc(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                         int K, int ldx, int ldy, int ldr, void* stream);
+int stcat_linear_dgrad_acc(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
+                           int lddx, void* stream);
 /* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0.  db (may be NULL; caller-zeroed,
  * needs ldg == N) += column sums of g — the bias gradient of the same nn.Linear, summed inside the launch */
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,

@@ -35,6 +35,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_sine_embed_bwd": "ppppis",
     "stcat_linear_fwd": "pppppiiiiiiiils",
     "stcat_linear_dgrad": "pppppiiiiis",
+    "stcat_linear_fwd_acc": "pppppiiiiiis",
+    "stcat_linear_dgrad_acc": "ppppiiiiis",
     "stcat_linear_wgrad": "ppppiiiiis",
     "stcat_small_linear_fwd": "ppppiiis",
     "stcat_small_linear_bwd": "ppppppiiis",

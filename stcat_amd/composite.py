@@ -76,12 +76,17 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
     dx = None
     if N % 64 == 0:
         if need_dx:
-            dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
-            wt = ops.weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
             if add is not None:
                 add = add.reshape(M, K)
                 add = add if add.is_contiguous() else add.contiguous()
-            L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), L._ptr(add), L._ptr(wt), dx.data_ptr(), M, N, K, N, K, st)
+            arena = ops._ARENA.get(str(g.device)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32") else None
+            dx = arena.take((M, K)) if arena is not None else None
+            if dx is not None:       # skinny: zeroed output, reduction split over grid.z (see ops.linear_fwd_raw)
+                L.call("stcat_linear_dgrad_acc", g.data_ptr(), w.data_ptr(), L._ptr(add), dx.data_ptr(), M, N, K, N, K, st)
+            else:
+                dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+                wt = ops.weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
+                L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), L._ptr(add), L._ptr(wt), dx.data_ptr(), M, N, K, N, K, st)
         if dw is None:
             dw = ops._zeros(g, N, K)
         if db is None and want_db:

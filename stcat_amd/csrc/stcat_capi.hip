@@ -152,14 +152,17 @@ static bool sk_wanted(const IgemmParams& p, int workers) {
 // Skinny launches with a long reduction (FFN of the decoders / temporal encoder on [T(+1),256] states, K = 2048): 4-8 workgroups
 // walking 64 K-tiles each is ~35 us of pure latency; split the reduction over grid.z into >= 8-tile slices that
 // add into the zeroed output.  Only when the epilogue is bias / residual (no scale, ReLU, mask, second output).
+static bool g_acc_output = false;  // set by the *_acc entries around the launch: C already holds the value to add onto
 static int skinny_splits(const IgemmParams& p) {
-  if (!(bs_ok(p) && p.M <= 128 && p.K >= 1024 && !p.scale && !p.relu && !p.mask && !p.C2 && p.c_group >= p.M)) return 0;
+  const int min_k = g_acc_output ? 128 : 1024;   // without the memset launch a 4-K-tile reduction is worth splitting too
+  if (!(bs_ok(p) && p.M <= 128 && p.K >= min_k && !p.scale && !p.relu && !p.mask && !p.C2 && p.c_group >= p.M)) return 0;
   const int nk = p.K / 32;
-  int splits = nk / 8;
+  int splits = g_acc_output ? nk / 2 : nk / 8;
   if (splits > 8) splits = 8;
   return splits >= 2 ? splits : 0;
 }
 static int skinny_zero(const IgemmParams& p, hipStream_t st) {
+  if (g_acc_output) return 0;
   for (int m = 0; m < (p.ldc == p.N ? 1 : p.M); ++m) {  // dense output: one memset, else row by row
     const size_t bytes = (p.ldc == p.N ? (size_t)p.M * p.N : (size_t)p.N) * sizeof(float);
     if (hipMemsetAsync(p.C + (size_t)m * p.ldc, 0, bytes, st) != hipSuccess) return fail("split-K: memset failed");
@@ -596,6 +599,29 @@ int stcat_linear_dgrad(const float* g, const float* w, const float* add, const f
     return launch_fwd(p, (hipStream_t)stream);
   }
   return launch_dgrad(p, (hipStream_t)stream);
+}
+
+// y += x w^T + bias (+ res), dx += g w (+ add): the output already holds the value to accumulate onto (zeros from the
+// caller's zeroed arena in the decoders).  For the skinny launches of the decoders (M <= 128) the reduction can then be
+// split over grid.z without a memset launch in front; other shapes are refused (no beta = 1 epilogue in the big tiles).
+int stcat_linear_fwd_acc(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                         int K, int ldx, int ldy, int ldr, void* stream) {
+  if (M > 128 || K < 128 || K % 64 != 0 || g_mma_mode == 0)
+    return fail("linear_fwd_acc: the accumulate form serves M <= 128, K >= 128, K %% 64 == 0 in the split-bf16 modes (M=%d K=%d)", M, K);
+  g_acc_output = true;
+  const int rc = stcat_linear_fwd(x, w, bias, res, y, M, N, K, ldx, ldy, ldr, 0, 0, 0, stream);
+  g_acc_output = false;
+  return rc;
+}
+
+int stcat_linear_dgrad_acc(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
+                           int lddx, void* stream) {
+  if (M > 128 || N < 128 || N % 64 != 0 || g_mma_mode == 0)
+    return fail("linear_dgrad_acc: the accumulate form serves M <= 128, N >= 128, N %% 64 == 0 in the split-bf16 modes (M=%d N=%d)", M, N);
+  g_acc_output = true;
+  const int rc = stcat_linear_dgrad(g, w, add, nullptr, dx, M, N, K, ldg, lddx, stream);
+  g_acc_output = false;
+  return rc;
 }
 
 int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);

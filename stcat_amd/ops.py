@@ -195,6 +195,16 @@ def linear_fwd_raw(x2d, w, bias, res2d=None, relu=False, out=None, ldy=None, c_g
     N = w.shape[0]
     _chk(x2d, w, bias, res2d)
     if out is None:
+        # the decoders' skinny launches ([T,256] states): output taken from the step's zeroed arena, reduction split
+        # over grid.z with an atomic epilogue — 8 serial K-tiles on 4 workgroups are pure latency otherwise
+        if (M <= 128 and K >= 128 and K % 64 == 0 and N % 64 == 0 and not relu and c_group == 0 and ldy is None
+                and L.get_mma_mode() != "f32" and x2d.is_contiguous()):
+            a = _ARENA.get(str(x2d.device))
+            out = a.take((M, N)) if a is not None else None
+            if out is not None:
+                L.call("stcat_linear_fwd_acc", x2d.data_ptr(), w.data_ptr(), L._ptr(bias), L._ptr(res2d), out.data_ptr(), M, N, K,
+                       K, N, (res2d.stride(0) if res2d is not None else 0), L.stream_of(x2d))
+                return out
         out = _empty(x2d, M, N)
     ldy = N if ldy is None else ldy
     if N % 64 == 0:

@@ -851,3 +851,30 @@ def _stg_loss(dev, big):
     if big:
         _stg_loss_case(dev, 64, 6, 10, 50, seed=4)
         _stg_loss_case(dev, 200, 6, 0, 120, seed=5)            # MAX_VIDEO_LEN
+
+
+@both
+def _linear_skinny_accumulate(dev, big):
+    """the decoders' skinny launches with the step's zero arena on: outputs come zeroed from the arena and the reduction
+    is split over grid.z (stcat_linear_fwd_acc / stcat_linear_dgrad_acc), forward with bias + residual, data gradient
+    with the fused `add` operand"""
+    from stcat_amd import composite
+    arena = ops.enable_zero_arena(dev, 1 << 21)
+    try:
+        with mma_mode("bf16x3", 1e-3):
+            for (M, N, K, res) in ((64, 256, 256, True), (65, 256, 2048, True), (37, 128, 128, False), (8, 2048, 256, False)):
+                x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+                r = rnd(M, N, seed=4) if res else None
+                used = arena.off
+                y = ops.linear_fwd_raw(x.to(dev), w.to(dev), b.to(dev), r.to(dev) if res else None)
+                assert arena.off > used, "the accumulate path did not take its output from the arena"
+                ref = F.linear(x, w, b) + (r if res else 0)
+                close(y, ref, TOL, f"skinny fwd {M}x{N}x{K}")
+                g, add = rnd(M, N, seed=5), rnd(M, K, seed=6)
+                dx, dw, db, _ = composite._lin_b(g.to(dev), x.to(dev), w.to(dev), add=add.to(dev))
+                close(dx, g @ w + add, TOL, f"skinny dgrad {M}x{N}x{K}")
+                close(dw, g.t() @ x, TOL, f"skinny wgrad {M}x{N}x{K}")
+                close(db, g.sum(0), TOL, f"skinny bias grad {M}x{N}x{K}")
+                arena.reset()
+    finally:
+        ops.disable_zero_arena()
