@@ -146,27 +146,33 @@ class _BackboneFn(Function):
         grads = {}
         tape = ctx.tape
         # transposed weights for every data-gradient GEMM of this pass: one launch (ops.WeightTransposer)
-        wts = {}
-        if ops.L.get_mma_mode() != "f32":
-            ws = [w for rec in tape for w in rec[5] if w is not None]
-            wts = ctx.body._wt_cache.refresh(ws)
+        ws = [w for rec in tape for w in rec[5] if w is not None]
+        wts = ctx.body._wt_cache.refresh(ws)
         _wt = lambda w: wts.get(w.data_ptr())  # noqa: E731
+        # weight gradients on a second stream behind the data-gradient chain (see _BackboneFnPl.backward)
+        wg = ops.WgradStream(dy)
+
+        def wgrad(key, g, xin, wshape, stride, pad):
+            with wg:
+                grads[key] = ops.conv_wgrad_raw(g, xin, wshape, stride, pad)
+            wg.keep(g, xin)
+
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
         # top of the stack: dz = dy * [y > 0] (identity-path gradient), g3 = dz * scale3 (conv3 upstream)
         g3, dz = ops.act_bwd_raw(dy.contiguous(), y, s3, want_g=True, want_res=True, relu=True)
         for idx in range(len(tape) - 1, -1, -1):
             blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd) = tape[idx]
             need_dx = idx > 0  # below the first trainable block everything is frozen (backbone.py:78-85)
-            grads[id(blk.conv3.weight)] = ops.conv_wgrad_raw(g3, o2, w3.shape, 1, 0)
+            wgrad(id(blk.conv3.weight), g3, o2, w3.shape, 1, 0)
             # each dgrad epilogue applies the ReLU+BN backward of the layer below (no intermediate dO tensor)
             g2 = ops.conv_dgrad_raw(g3, w3, o2.shape, 1, 0, mask_y=o2, mask_scale=s2, wt=_wt(w3))
-            grads[id(blk.conv2.weight)] = ops.conv_wgrad_raw(g2, o1, w2.shape, blk.stride, 1)
+            wgrad(id(blk.conv2.weight), g2, o1, w2.shape, blk.stride, 1)
             g1 = ops.conv_dgrad_raw(g2, w2, o1.shape, blk.stride, 1, mask_y=o1, mask_scale=s1, wt=_wt(w2))
-            grads[id(blk.conv1.weight)] = ops.conv_wgrad_raw(g1, x, w1.shape, 1, 0)
+            wgrad(id(blk.conv1.weight), g1, x, w1.shape, 1, 0)
             gd = None
             if wd is not None:
                 gd, _ = ops.act_bwd_raw(dz, None, sd, want_g=True, relu=False)  # dz * scale_downsample
-                grads[id(blk.downsample[0].weight)] = ops.conv_wgrad_raw(gd, x, wd.shape, blk.stride, 0)
+                wgrad(id(blk.downsample[0].weight), gd, x, wd.shape, blk.stride, 0)
             if not need_dx:
                 break
             # block boundary: x is the ReLU output of the block below; its dz / g3 come out of this epilogue
@@ -176,6 +182,7 @@ class _BackboneFn(Function):
                 dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=part, out=part, mask_y=x, scale2=s3_below, wt=_wt(w1))
             else:
                 dz, g3 = ops.conv_dgrad_raw(g1, w1, x.shape, 1, 0, add=dz, mask_y=x, scale2=s3_below, wt=_wt(w1))
+        wg.join(*grads.values())
         out = []
         for w in ctx.plist:  # same order as the *weights passed to forward
             g = grads.get(id(w))

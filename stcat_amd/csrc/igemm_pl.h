@@ -46,6 +46,11 @@ struct PlParams {
   unsigned a_bytes, b_bytes;            // extent of ONE plane of A / B (bytes)
   unsigned b_tap_stride;                // elements
   int k_chunk;                          // wgrad: pixels of the reduction per grid.z slice (multiple of 32)
+  // exact-fp32 form (template parameter F32): the A / B "planes" are the fp32 tensors themselves, addressed in units of
+  // half a float (the caller doubles C, ld, ldb, b_tap_stride, K), products on v_mfma_f32_32x32x2_f32; epilogue operands fp32
+  const float* Rf;                      // residual [M][ldr]
+  const float* Yf;                      // dgrad mask source y [M][ldc]
+  float* C2f;                           // second scaled output
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
   const float* wscale;                  // wgrad: optional per-row factor dW[m][:] *= wscale[m] (a FrozenBN scale folded out of dY)
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
@@ -60,6 +65,11 @@ static __device__ __forceinline__ void stcat_split8(const float (&v)[8], bf16x8&
     h[e] = hh;
     l[e] = (__bf16)(v[e] - (float)hh);
   }
+}
+// float e (0..3) of a 16-byte fragment register
+static __device__ __forceinline__ float stcat_f4(const bf16x8& v, int e) {
+  const float4 f = __builtin_bit_cast(float4, v);
+  return e == 0 ? f.x : (e == 1 ? f.y : (e == 2 ? f.z : f.w));
 }
 static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf16* lp, float (&v)[8]) {
   const bf16x8 h = *reinterpret_cast<const bf16x8*>(hp), l = *reinterpret_cast<const bf16x8*>(lp);
@@ -96,6 +106,20 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
     for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.ah[tm], F.bh[tn], acc[tm][tn]); \
   }
 
+// exact-fp32 form: a 16-byte fragment is FOUR fp32 reduction terms of the lane's row (the lane pair (l31, hi) covers 8
+// consecutive k: hi = 0 the first four, hi = 1 the last four — the MFMA's own k index (= hi) just has to pair the same
+// term of A and B); four v_mfma_f32_32x32x2_f32 per fragment pair, k-term outermost
+#define STCAT_PL_MMA_F32(F)                                                                             \
+  STCAT_UNROLL                                                                                          \
+  for (int e = 0; e < 4; ++e) {                                                                         \
+    STCAT_UNROLL                                                                                        \
+    for (int tm = 0; tm < TM; ++tm) {                                                                   \
+      STCAT_UNROLL                                                                                      \
+      for (int tn = 0; tn < TN; ++tn)                                                                   \
+        acc[tm][tn] = STCAT_MFMA_32x32x2(stcat_f4(F.ah[tm], e), stcat_f4(F.bh[tn], e), acc[tm][tn]);    \
+    }                                                                                                   \
+  }
+
 // interleave request for the block [DMA | fragment reads | MFMAs] that follows: NV DMA instructions and ND fragment
 // reads spread over NM MFMAs.  Measured (probe V8/V9): with the 8 DMA instructions clustered behind the barrier both
 // waves of a SIMD sit in address/M0 set-up while the matrix pipe idles (-12 %).
@@ -112,7 +136,7 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
 // forward / data gradient:  C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (tap, c), c fastest
 // 8 waves as WM x WN, wave tile (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32 x 32.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool F32 = false>
 __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   static_assert(WM * WN == 8, "8 waves");
   constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
@@ -174,14 +198,14 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       const unsigned vo_ = ok_ ? (unsigned)(((a_nb[i] * g.H + h_) * g.W + w_) * g.ld) * 2u + a_c16[i] : STCAT_BUF_OOB; \
       if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
         stcat_glds16(dAh_, base_ + i * 8192, vo_, soA_);                                                \
-        stcat_glds16(dAl_, base_ + PLANE_A + i * 8192, vo_, soA_);                                      \
+        if (!F32) stcat_glds16(dAl_, base_ + PLANE_A + i * 8192, vo_, soA_);                            \
       }                                                                                                 \
     }                                                                                                   \
     STCAT_UNROLL                                                                                        \
     for (int i = 0; i < RQB; ++i) {                                                                     \
       if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
         stcat_glds16(dBh_, base_ + 2 * PLANE_A + i * 8192, b_voff[i], soB_);                            \
-        stcat_glds16(dBl_, base_ + 2 * PLANE_A + PLANE_B + i * 8192, b_voff[i], soB_);                  \
+        if (!F32) stcat_glds16(dBl_, base_ + 2 * PLANE_A + PLANE_B + i * 8192, b_voff[i], soB_);        \
       }                                                                                                 \
     }                                                                                                   \
     ++kl; l_c0 += BK;                                                                                   \
@@ -201,17 +225,17 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   STCAT_UNROLL                                                                                          \
   for (int tn = 0; tn < TN; ++tn) {                                                                     \
     F.bh[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + tn * 2048);                         \
-    F.bl[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + PLANE_B + tn * 2048);               \
+    if (!F32) F.bl[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + PLANE_B + tn * 2048);     \
   }                                                                                                     \
   STCAT_UNROLL                                                                                          \
   for (int tm = 0; tm < TM; ++tm) {                                                                     \
     F.ah[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + tm * 2048);                         \
-    F.al[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + PLANE_A + tm * 2048);               \
+    if (!F32) F.al[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + PLANE_A + tm * 2048);     \
   }
 
   STCAT_PL_ACC_INIT
-  constexpr int NMMA = 3 * TM * TN, NRD = 2 * (TM + TN);
-  constexpr int NDMA = 2 * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  constexpr int NMMA = (F32 ? 4 : 3) * TM * TN, NRD = (F32 ? 1 : 2) * (TM + TN);
+  constexpr int NDMA = (F32 ? 1 : 2) * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
   Frag fa, fb;
   STCAT_PL_STAGE_LOAD(0)
   STCAT_PL_STAGE_LOAD(1)
@@ -225,7 +249,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     // P0: k-step 1 fragments are read among the MFMAs of k-step 0
     STCAT_PL_READ_FRAG(fb, sb, 1)
     STCAT_PL_INTERLEAVE(NMMA, NRD, 0)
-    STCAT_PL_MMA(fa)
+    if constexpr (F32) { STCAT_PL_MMA_F32(fa) } else { STCAT_PL_MMA(fa) }
     STCAT_SCHED_FENCE();
     // P1: own reads of this stage are back (the MFMAs below need fb anyway), tile kt+1 has landed, and after the
     // barrier every wave is past its reads of this stage: its buffer takes tile kt+2
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     STCAT_PL_STAGE_LOAD(kt & 1)
     STCAT_PL_READ_FRAG(fa, sn, 0)
     STCAT_PL_INTERLEAVE(NMMA, NRD, NDMA)
-    STCAT_PL_MMA(fb)
+    if constexpr (F32) { STCAT_PL_MMA_F32(fb) } else { STCAT_PL_MMA(fb) }
     STCAT_SCHED_FENCE();
   }
 #undef STCAT_PL_STAGE_LOAD
@@ -280,6 +304,9 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
           stcat_join8(p.Rh + (long)m * p.ldr + n, p.Rl + (long)m * p.ldr + n, rr);
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] += rr[e];
+        } else if (F32 && p.Rf) {
+          const float4 r0 = stcat_ld4(p.Rf + (long)m * p.ldr + n), r1 = stcat_ld4(p.Rf + (long)m * p.ldr + n + 4);
+          x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
         }
         if (p.relu) {
           STCAT_UNROLL
@@ -292,6 +319,11 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
         } else if (p.Yh) {
           float yy[8];
           stcat_join8(p.Yh + (long)m * p.ldc + n, p.Yl + (long)m * p.ldc + n, yy);
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] = yy[e] > 0.f ? x[e] * ms[e] : 0.f;
+        } else if (F32 && p.Yf) {
+          const float4 y0 = stcat_ld4(p.Yf + (long)m * p.ldc + n), y1 = stcat_ld4(p.Yf + (long)m * p.ldc + n + 4);
+          const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = yy[e] > 0.f ? x[e] * ms[e] : 0.f;
         }
@@ -310,6 +342,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
         if (p.Cf) {
           stcat_st4(p.Cf + (long)m * p.ldc + n, make_float4(x[0], x[1], x[2], x[3]));
           stcat_st4(p.Cf + (long)m * p.ldc + n + 4, make_float4(x[4], x[5], x[6], x[7]));
+        }
+        if (F32 && p.C2f) {
+          stcat_st4(p.C2f + (long)m * p.ldc + n, make_float4(x[0] * s2[0], x[1] * s2[1], x[2] * s2[2], x[3] * s2[3]));
+          stcat_st4(p.C2f + (long)m * p.ldc + n + 4, make_float4(x[4] * s2[4], x[5] * s2[5], x[6] * s2[6], x[7] * s2[7]));
         }
         if (p.C2h) {
           STCAT_UNROLL

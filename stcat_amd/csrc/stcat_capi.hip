@@ -170,7 +170,11 @@ static int skinny_zero(const IgemmParams& p, hipStream_t st) {
   return 0;
 }
 
+int launch_pl_fwd_f32(const IgemmParams& p, hipStream_t st);
+bool pl_f32_ok(const IgemmParams& p);
+
 int launch_fwd(const IgemmParams& p, hipStream_t st) {
+  if (g_mma_mode == 0 && pl_f32_ok(p)) return launch_pl_fwd_f32(p, st);  // exact-fp32 mode on the LDS-DMA structure
   if (const int splits = skinny_splits(p)) {
     IgemmParams q = p;
     q.k_chunk = cdiv(p.K / 32, splits);
@@ -361,6 +365,64 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   return launch_status();
 }
 
+// ---- exact-fp32 mode through the same kernel (template parameter F32): the fp32 tensors are addressed in units of
+// half a float, so gather, DMA, swizzle and fragment reads are the plane kernel's; the K-step of 32 units is 16 fp32
+// reduction terms on v_mfma_f32_32x32x2_f32.  Conv forward, conv / Linear data gradient on pre-transposed weights and
+// the large Linear layers of the encoder come through here in mma mode "f32".
+bool pl_f32_ok(const IgemmParams& p) {
+  return !g_force_bm && p.M >= 256 && p.g.C % 16 == 0 && p.N % 64 == 0 && p.K % 16 == 0 && p.c_group >= p.M &&
+         p.a_bytes != 0xFFFFFFFFu && p.b_bytes != 0xFFFFFFFFu && p.ldc % 4 == 0 && p.ldb % 4 == 0 && p.g.ld % 4 == 0 &&
+         (!p.res || p.ldr % 4 == 0) && aligned16(p.A) && aligned16(p.B) && aligned16(p.C) && (!p.res || aligned16(p.res)) &&
+         (!p.mask || aligned16(p.mask)) && (!p.C2 || aligned16(p.C2)) && !p.sk_ws;
+}
+
+int launch_pl_fwd_f32(const IgemmParams& s, hipStream_t st) {
+  PlParams p = {};
+  p.Ah = reinterpret_cast<const __bf16*>(s.A); p.Bh = reinterpret_cast<const __bf16*>(s.B);
+  p.Cf = s.C; p.scale = s.scale; p.bias = s.bias; p.Rf = s.res; p.Yf = s.mask; p.mscale = s.mscale;
+  p.C2f = s.C2; p.c2scale = s.c2scale;
+  p.M = s.M; p.N = s.N; p.K = 2 * s.K; p.ldb = 2 * s.ldb; p.ldc = s.ldc; p.ldr = s.ldr; p.relu = s.relu;
+  p.a_bytes = s.a_bytes; p.b_bytes = s.b_bytes;
+  p.b_tap_stride = s.b_tap_stride / 2;          // bytes -> half-float units
+  p.g = s.g;
+  p.g.C = 2 * s.g.C; p.g.ld = 2 * s.g.ld;
+  stcat_fastdiv_magic(p.g.OW, &p.g.mg_ow, &p.g.sh_ow);
+  stcat_fastdiv_magic(p.g.OH * p.g.OW, &p.g.mg_ohw, &p.g.sh_ohw);
+  p.debug = g_pl_debug;
+  // tile: the rounds x area cost model (the fp32 pipe is 5x slower per product than bf16x3: every shape is matrix-bound)
+  int ti = -1;
+  float best = 0.f;
+  for (int i = 0; i < 6; ++i) {
+    const PlTile& tl = kPlTiles[i];
+    if (p.N % tl.bn != 0) continue;
+    const long tiles = (long)cdiv(p.M, tl.bm) * (p.N / tl.bn);
+    // (224 x 256: its 1 x 8 wave layout re-reads the A fragments 8x — irrelevant here, 4 fp32 MFMAs = 256 cycles per
+    // fragment pair; what counts is that 50176 = 224 * 224 rows of layer3 fill 224 of the 256 CUs in one round)
+    const float cost = (float)((tiles + 255) / 256) * tl.bm * tl.bn * (i == 5 ? 1.0f : tl.eff);
+    if (ti < 0 || cost < best) { ti = i; best = cost; }
+  }
+  if (g_pl_force >= 0 && g_pl_force < 6 && p.N % kPlTiles[g_pl_force].bn == 0) ti = g_pl_force;
+  if (ti < 0) return fail("fp32 plane GEMM: N = %d is not a multiple of 64", p.N);
+  const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
+  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+#define STCAT_PLF_LAUNCH(BM_, BN_, WM_, WN_)                                                          \
+  {                                                                                                    \
+    constexpr int lds_ = 4 * (BM_ + BN_) * 64;                                                         \
+    if (int rc_ = pl_prepare(igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, true>, lds_)) return rc_;         \
+    STCAT_LAUNCH((igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(512), lds_, st, p);       \
+  }
+  switch (ti) {
+    case 0: STCAT_PLF_LAUNCH(256, 256, 2, 4) break;
+    case 1: STCAT_PLF_LAUNCH(256, 128, 4, 2) break;
+    case 2: STCAT_PLF_LAUNCH(128, 256, 2, 4) break;
+    case 3: STCAT_PLF_LAUNCH(128, 128, 2, 4) break;
+    case 5: STCAT_PLF_LAUNCH(224, 256, 1, 8) break;
+    default: STCAT_PLF_LAUNCH(256, 64, 8, 1) break;
+  }
+#undef STCAT_PLF_LAUNCH
+  return launch_status();
+}
+
 // rows = Cout, cols = taps * Cin, red = pixels
 int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   if (rows % 128 != 0 || p.g.C % 128 != 0) return fail("plane wgrad: need Cout, Cin %% 128 == 0 (%d, %d)", rows, p.g.C);
@@ -500,10 +562,11 @@ int stcat_conv_dgrad(const float* g, const float* w, const float* add, const flo
   q.H = OH; q.W = OW; q.C = Cout; q.ld = Cout; q.OH = H; q.OW = W; q.KH = KH; q.KW = KW;
   q.mul = 1; q.off = pad; q.sgn = -1; q.div = stride;
   p.g = q;
-  if (wt && g_mma_mode != 0 && bs_ok(p)) {  // transposed weights [tap][Cin][Cout]: the forward kernel's staging path
-    p.B = wt; p.ldb = Cout; p.b_tap_stride = (unsigned)((long)Cin * Cout * 4);
-    p.c_group = p.M;
-    return launch_fwd(p, (hipStream_t)stream);
+  if (wt && ((g_mma_mode != 0 && bs_ok(p)) || g_mma_mode == 0)) {  // transposed weights [tap][Cin][Cout]: the forward
+    IgemmParams t = p;                                              // kernel's staging path
+    t.B = wt; t.ldb = Cout; t.b_tap_stride = (unsigned)((long)Cin * Cout * 4);
+    t.c_group = t.M;
+    if (g_mma_mode != 0 || pl_f32_ok(t)) return launch_fwd(t, (hipStream_t)stream);
   }
   return launch_dgrad(p, (hipStream_t)stream);
 }
@@ -594,9 +657,10 @@ int stcat_linear_dgrad(const float* g, const float* w, const float* add, const f
   q.H = 1; q.W = 1; q.C = N; q.ld = ldg; q.OH = 1; q.OW = 1; q.KH = 1; q.KW = 1;
   q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
   p.g = q;
-  if (wt && g_mma_mode != 0 && bs_ok(p)) {  // wt = w^T [K][N]
-    p.B = wt; p.ldb = N; p.b_tap_stride = 0;
-    return launch_fwd(p, (hipStream_t)stream);
+  if (wt && ((g_mma_mode != 0 && bs_ok(p)) || g_mma_mode == 0)) {  // wt = w^T [K][N]
+    IgemmParams t = p;
+    t.B = wt; t.ldb = N; t.b_tap_stride = 0;
+    if (g_mma_mode != 0 || pl_f32_ok(t)) return launch_fwd(t, (hipStream_t)stream);
   }
   return launch_dgrad(p, (hipStream_t)stream);
 }

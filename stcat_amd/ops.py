@@ -314,7 +314,7 @@ class LinearFn(Function):
         if N % 64 == 0:
             if ctx.needs_input_grad[0]:
                 dx = _empty(g, M, K)
-                wt = weight_transpose(w.view(N, 1, K)) if (L.get_mma_mode() != "f32" and M > 256) else None
+                wt = weight_transpose(w.view(N, 1, K)) if M > 256 else None
                 L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, L._ptr(wt), dx.data_ptr(), M, N, K, N,
                        K, st)
             want_db = ctx.has_b and ctx.needs_input_grad[2]
@@ -972,7 +972,7 @@ def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None, mask_y=
     Cout, KH, KW, _ = w_ohwi.shape
     dx = _empty(g, n, H, W, Cin) if out is None else out
     dx2 = _empty(g, n, H, W, Cin) if scale2 is not None else None
-    if wt is None and L.get_mma_mode() != "f32":
+    if wt is None:
         wt = weight_transpose(w_ohwi.view(Cout, KH * KW, Cin))
     L.call("stcat_conv_dgrad", g.data_ptr(), w_ohwi.data_ptr(), L._ptr(add), L._ptr(mask_y), L._ptr(mask_scale),
            dx.data_ptr(), L._ptr(dx2), L._ptr(scale2), L._ptr(wt), n, H, W, Cin, Cout, KH, KW, stride, pad,

@@ -878,3 +878,31 @@ def _linear_skinny_accumulate(dev, big):
                 arena.reset()
     finally:
         ops.disable_zero_arena()
+
+
+@both
+def _gemm_f32_lds_dma(dev, big):
+    """exact-fp32 mode on the LDS-DMA kernel (igemm_pl_fwd_kernel<..., F32>): launches with >= 256 rows — padded 3x3,
+    strided 3x3 and 1x1, residual + ReLU, ragged row tails, every tile shape, the data gradient on transposed weights
+    with the fused mask / add operands, and Linear layers"""
+    assert L.get_mma_mode() == "f32"
+    _conv_case(dev, 2, 13, 11, 64, 128, 3, 1, 1, relu=True, res=True)          # M = 286
+    _conv_case(dev, 1, 18, 17, 64, 256, 1, 2, 0, relu=False, res=False)
+    _conv_case(dev, 1, 23, 21, 64, 64, 3, 2, 1, relu=True, res=False)
+    _conv_case(dev, 3, 10, 10, 128, 64, 1, 1, 0, relu=True, res=True)
+    _linear_case(dev, 300, 128, 64, relu=True, res=True)
+    _linear_case(dev, 1000, 256, 128, relu=False, res=False)
+    _linear_case(dev, 257, 64, 256, relu=False, res=True)
+    for t in range(6):
+        L.call("stcat_debug_force_pl_tile", t)
+        try:
+            _conv_case(dev, 1, 19, 17, 64, 256, 3, 1, 1, relu=True, res=True)
+            _linear_case(dev, 515, 256, 64, relu=True, res=False)
+        finally:
+            L.call("stcat_debug_force_pl_tile", -1)
+    if big:
+        _conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
+        _conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False)
+        _conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True)
+        _linear_case(dev, 13248, 2048, 256, relu=True, res=False)
+        _linear_case(dev, 13248, 256, 2048, relu=False, res=True)

@@ -8,28 +8,44 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NACC>
+template <int NACC, int RANDOM>
 __global__ void __launch_bounds__(512) k_f32(float* out, int iters) {
   f32x16 acc[NACC];
   for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  float a = threadIdx.x * 1e-3f, b = 1.f + blockIdx.x * 1e-6f;
+  // operands: RANDOM == 0: two constants (little switching activity); 1: per-lane pseudo-random values, a different
+  // pair for every accumulator (what a GEMM on real data feeds the pipe)
+  float av[NACC], bv[NACC];
+  unsigned h = (threadIdx.x + 1) * 2654435761u ^ (blockIdx.x * 40503u);
+  for (int i = 0; i < NACC; ++i) {
+    h = h * 1664525u + 1013904223u;
+    av[i] = RANDOM ? (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f : threadIdx.x * 1e-3f;
+    h = h * 1664525u + 1013904223u;
+    bv[i] = RANDOM ? (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f : 1.f + blockIdx.x * 1e-6f;
+  }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc[i], 0, 0, 0);
   }
   float s = 0.f;
   for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
   if (s == 123.456f) out[0] = s;
 }
-template <int NACC>
+template <int NACC, int RANDOM>
 __global__ void __launch_bounds__(512) k_bf16(float* out, int iters) {
   f32x16 acc[NACC];
   for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  bf16x8 a, b;
-  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(threadIdx.x * 1e-3f + j); b[j] = (__bf16)(1.f + j); }
+  bf16x8 av[NACC], bv[NACC];
+  unsigned h = (threadIdx.x + 1) * 2654435761u ^ (blockIdx.x * 40503u);
+  for (int i = 0; i < NACC; ++i)
+    for (int j = 0; j < 8; ++j) {
+      h = h * 1664525u + 1013904223u;
+      av[i][j] = (__bf16)(RANDOM ? (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f : threadIdx.x * 1e-3f + j);
+      h = h * 1664525u + 1013904223u;
+      bv[i][j] = (__bf16)(RANDOM ? (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f : 1.f + j);
+    }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[i], acc[i], 0, 0, 0);
   }
   float s = 0.f;
   for (int i = 0; i < NACC; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
@@ -58,17 +74,17 @@ double run(K kern, int threads, int wgs, int iters, double flop_per_mfma, int na
 
 int main() {
   // long enough to reach the sustained (power-managed) clock: ~50-100 ms per launch
-  printf("fp32  v_mfma_f32_32x32x2_f32 (nominal 157.3 TF)\n");
-  for (int wpc : {1, 2}) {
-    double t4 = run(k_f32<4>, 256, 256 * wpc, 400000 / wpc, 4096.0, 4);
-    double t8 = run(k_f32<4>, 512, 256 * wpc, 200000 / wpc, 4096.0, 4);
-    printf("  %d WG/CU: 4 waves/WG %.1f TF (%.0f %%), 8 waves/WG %.1f TF (%.0f %%)\n", wpc, t4, 100 * t4 / 157.3, t8, 100 * t8 / 157.3);
+  printf("fp32  v_mfma_f32_32x32x2_f32 (nominal 157.3 TF), 8 waves/WG, 1 WG/CU\n");
+  {
+    double c = run(k_f32<4, 0>, 512, 256, 200000, 4096.0, 4);
+    double r = run(k_f32<4, 1>, 512, 256, 200000, 4096.0, 4);
+    printf("  constant operands %.1f TF (%.0f %%), random operands %.1f TF (%.0f %%)\n", c, 100 * c / 157.3, r, 100 * r / 157.3);
   }
-  printf("bf16  v_mfma_f32_32x32x16_bf16 (nominal 2516 TF)\n");
-  for (int wpc : {1, 2}) {
-    double t4 = run(k_bf16<4>, 256, 256 * wpc, 800000 / wpc, 32768.0, 4);
-    double t8 = run(k_bf16<4>, 512, 256 * wpc, 400000 / wpc, 32768.0, 4);
-    printf("  %d WG/CU: 4 waves/WG %.1f TF (%.0f %%), 8 waves/WG %.1f TF (%.0f %%)\n", wpc, t4, 100 * t4 / 2516, t8, 100 * t8 / 2516);
+  printf("bf16  v_mfma_f32_32x32x16_bf16 (nominal 2516 TF), 8 waves/WG, 1 WG/CU\n");
+  {
+    double c = run(k_bf16<4, 0>, 512, 256, 400000, 32768.0, 4);
+    double r = run(k_bf16<4, 1>, 512, 256, 400000, 32768.0, 4);
+    printf("  constant operands %.1f TF (%.0f %%), random operands %.1f TF (%.0f %%)\n", c, 100 * c / 2516, r, 100 * r / 2516);
   }
   return 0;
 }
