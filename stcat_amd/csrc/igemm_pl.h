@@ -45,6 +45,10 @@ struct PlParams {
   int M, N, K, ldb, ldc, ldr, relu;
   unsigned a_bytes, b_bytes;            // extent of ONE plane of A / B (bytes)
   unsigned b_tap_stride;                // elements
+  int par;                              // fwd kernel, stride-2 data gradient on even H, W: rows are enumerated parity class by
+                                        // parity class ((y & 1, x & 1), M / 4 pixels each, whole tiles per class) so that a
+                                        // tile needs only the filter taps of its class — the lattice zeros (3/4 of the
+                                        // gathered rows otherwise) are never multiplied
   int k_chunk;                          // wgrad: pixels of the reduction per grid.z slice (multiple of 32)
   // exact-fp32 form (template parameter F32): the A / B "planes" are the fp32 tensors themselves, addressed in units of
   // half a float (the caller doubles C, ld, ldb, b_tap_stride, K), products on v_mfma_f32_32x32x2_f32; epilogue operands fp32
@@ -153,9 +157,19 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int num_n = p.N / BN;
   const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (v / num_n) * BM, n0 = (v % num_n) * BN;
   const IgemmGeom g = p.g;
-  const int nk = p.K / BK;
+  // row space: plain = pixel index m; parity form = (class, index inside the class), whole tiles per class
+  const int Mc = p.par ? p.M >> 2 : p.M;                    // rows per class
+  const int tpc = (Mc + BM - 1) / BM;                       // tiles per class
+  const int mt = v / num_n;
+  const int cls = p.par ? mt / tpc : 0, py = cls >> 1, px = cls & 1;
+  const int m0 = (mt - cls * tpc) * BM, n0 = (v % num_n) * BN;
+  const int OHc = p.par ? g.OH >> 1 : g.OH, OWc = p.par ? g.OW >> 1 : g.OW;
+  // filter taps that reach this class: (y + off - kh) even <=> kh = (py + off) mod 2 (mod 2); all taps in the plain form
+  const int kstep = p.par ? 2 : 1;
+  const int kh0 = p.par ? ((py + g.off) & 1) : 0, kw0 = p.par ? ((px + g.off) & 1) : 0;
+  const int nkh = kh0 < g.KH ? (g.KH - kh0 + kstep - 1) / kstep : 0, nkw = kw0 < g.KW ? (g.KW - kw0 + kstep - 1) / kstep : 0;
+  const int nk = p.par ? nkh * nkw * (g.C / BK) : p.K / BK;
 
   // ---- DMA bookkeeping: piece q = wave + 8 i covers rows 16 q .. 16 q + 15 of a plane; lane -> row 16 q + (lane >> 2),
   // LDS chunk (lane & 3) which holds SOURCE chunk (lane & 3) ^ ((row >> 2) & 3)
@@ -166,9 +180,18 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     const int q = wave + 8 * i, r = q * 16 + (lane >> 2), m = m0 + r;
     a_c16[i] = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16);
     a_nb[i] = -1; a_bh[i] = 0; a_bw[i] = 0;
-    if (q < QA && m < p.M) {
-      const int nb = stcat_fastdiv(m, g.mg_ohw, g.sh_ohw), rem = m - nb * g.OH * g.OW;
-      const int oh = stcat_fastdiv(rem, g.mg_ow, g.sh_ow), ow = rem - oh * g.OW;
+    if (q < QA && m < Mc) {
+      int nb, oh, ow;
+      if (p.par) {
+        nb = m / (OHc * OWc);
+        const int rem = m - nb * OHc * OWc;
+        oh = rem / OWc; ow = rem - oh * OWc;
+        oh = 2 * oh + py; ow = 2 * ow + px;
+      } else {
+        nb = stcat_fastdiv(m, g.mg_ohw, g.sh_ohw);
+        const int rem = m - nb * g.OH * g.OW;
+        oh = stcat_fastdiv(rem, g.mg_ow, g.sh_ow); ow = rem - oh * g.OW;
+      }
       a_nb[i] = nb; a_bh[i] = oh * g.mul + g.off; a_bw[i] = ow * g.mul + g.off;
     }
   }
@@ -180,7 +203,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   // load cursor: K-tile kl = (tap (kh, kw), channel offset c0); advances one tile per stage_load.  Tiles past the end
   // go through zero-length descriptors (zero fill into a stage nobody reads): the loop body stays branch-free, which
   // keeps the compiler's wait counts exact.
-  int kl = 0, l_c0 = 0, l_kh = 0, l_kw = 0, l_tap = 0;
+  int kl = 0, l_c0 = 0, l_kh = kh0, l_kw = kw0, l_tap = kh0 * g.KW + kw0;
   const int dmask = g.div - 1, dshift = g.div > 1 ? 31 - __builtin_clz(g.div) : 0;  // div is 1 or a power of two
 #define STCAT_PL_STAGE_LOAD(ST)                                                                         \
   {                                                                                                     \
@@ -209,7 +232,11 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       }                                                                                                 \
     }                                                                                                   \
     ++kl; l_c0 += BK;                                                                                   \
-    if (l_c0 == g.C) { l_c0 = 0; ++l_tap; ++l_kw; if (l_kw == g.KW) { l_kw = 0; ++l_kh; } }             \
+    if (l_c0 == g.C) {                                                                                  \
+      l_c0 = 0; l_kw += kstep;                                                                          \
+      if (l_kw >= g.KW) { l_kw = kw0; l_kh += kstep; }                                                  \
+      l_tap = l_kh * g.KW + l_kw;                                                                       \
+    }                                                                                                   \
   }
 
   // ---- fragment addressing: lane -> row l31 of its tile, k-step ks -> chunk (2 ks + hi) ^ ((row >> 2) & 3)
@@ -293,10 +320,15 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     STCAT_UNROLL
     for (int ps = 0; ps < 32 / RPP; ++ps) {
       const int row = ps * RPP + erow;
-      const int m = m0 + wm * TM * 32 + tm * 32 + row;
+      const int mrow = m0 + wm * TM * 32 + tm * 32 + row;
+      int m = mrow;                      // output row = pixel index
+      if (p.par && mrow < Mc) {
+        const int nb = mrow / (OHc * OWc), rem = mrow - nb * OHc * OWc, oh = rem / OWc, ow = rem - oh * OWc;
+        m = (nb * g.OH + 2 * oh + py) * g.OW + 2 * ow + px;
+      }
       const float4 v0 = stcat_ld4(&ew[row * LDE + ecol]), v1 = stcat_ld4(&ew[row * LDE + ecol + 4]);
       float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (m < p.M && !((p.debug & 2) && x[0] != 12345.f)) {
+      if (mrow < Mc && !((p.debug & 2) && x[0] != 12345.f)) {
         STCAT_UNROLL
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
         if (p.Rh) {

@@ -350,10 +350,13 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
-  const int ti = pick_pl_tile(p.M, p.N, p.K);
+  // stride-2 data gradient on even dims: parity-class row order (igemm_pl.h, PlParams::par): 4 x tiles(M / 4)
+  p.par = (p.g.div == 2 && p.g.mul == 1 && p.g.sgn == -1 && p.g.OH % 2 == 0 && p.g.OW % 2 == 0 && !(g_pl_debug & 4)) ? 1 : 0;
+  const int Mrows = p.par ? p.M / 4 : p.M;
+  const int ti = pick_pl_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K);
   if (ti < 0) return fail("plane GEMM: N = %d is not a multiple of 64", p.N);
   const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
-  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  const dim3 grid((p.par ? 4 : 1) * cdiv(Mrows, BM) * (p.N / BN));
   switch (ti) {
     case 0: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 256, 2, 4, grid) break;
     case 1: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 128, 4, 2, grid) break;
@@ -404,7 +407,8 @@ int launch_pl_fwd_f32(const IgemmParams& s, hipStream_t st) {
   if (g_pl_force >= 0 && g_pl_force < 6 && p.N % kPlTiles[g_pl_force].bn == 0) ti = g_pl_force;
   if (ti < 0) return fail("fp32 plane GEMM: N = %d is not a multiple of 64", p.N);
   const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
-  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  p.par = (p.g.div == 2 && p.g.mul == 1 && p.g.sgn == -1 && p.g.OH % 2 == 0 && p.g.OW % 2 == 0 && !(g_pl_debug & 4)) ? 1 : 0;
+  const dim3 grid((p.par ? 4 : 1) * cdiv(p.par ? p.M / 4 : p.M, BM) * (p.N / BN));
 #define STCAT_PLF_LAUNCH(BM_, BN_, WM_, WN_)                                                          \
   {                                                                                                    \
     constexpr int lds_ = 4 * (BM_ + BN_) * 64;                                                         \

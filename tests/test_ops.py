@@ -234,6 +234,10 @@ def _pl_conv(dev, big):
     _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=4, wgrad=False)
     _pl_conv_case(dev, 1, 8, 8, 64, 128, 3, 2, 1, relu=True, res=False, tile=3, wgrad=False)
     _pl_conv_case(dev, 1, 9, 7, 128, 128, 1, 2, 0, relu=False, res=False, tile=1)
+    # stride-2 data gradients on even dims run parity class by parity class (PlParams::par): 1x1 (three of the four
+    # classes have no tap at all), padded 3x3 with a ragged class size, two frames
+    _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=3)
+    _pl_conv_case(dev, 2, 6, 10, 64, 64, 3, 2, 1, relu=True, res=False, tile=4, wgrad=False)
     _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2)
     _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0)
     if big:
@@ -889,6 +893,8 @@ def _gemm_f32_lds_dma(dev, big):
     _conv_case(dev, 2, 13, 11, 64, 128, 3, 1, 1, relu=True, res=True)          # M = 286
     _conv_case(dev, 1, 18, 17, 64, 256, 1, 2, 0, relu=False, res=False)
     _conv_case(dev, 1, 23, 21, 64, 64, 3, 2, 1, relu=True, res=False)
+    _conv_case(dev, 1, 24, 22, 64, 64, 3, 2, 1, relu=True, res=False)           # even dims: parity-class data gradient
+    _conv_case(dev, 1, 18, 18, 64, 128, 1, 2, 0, relu=False, res=False)
     _conv_case(dev, 3, 10, 10, 128, 64, 1, 1, 0, relu=True, res=True)
     _linear_case(dev, 300, 128, 64, relu=True, res=True)
     _linear_case(dev, 1000, 256, 128, relu=False, res=False)
