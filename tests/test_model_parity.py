@@ -404,8 +404,12 @@ def test_gpu_uint8_frames_through_the_model():
             of = model(NestedTensor(f32.to(dev), mask, [T]), ["q"])
     finally:
         _lib.set_mma_mode("f32")
+    # The two stems round differently ((u/255 - mean)/std inside the gather vs. the pre-normalised tensor): 3e-3 of 117
+    # on the layer4 features in the bench's 16-bit-significand arithmetic, which reaches the heads as 2e-5 (boxes) to
+    # 4e-4 (actioness logits, scale 4.8); in exact-fp32 mode the same comparison gives 1e-6 .. 1e-5 (tools/u8_check.py).
+    # The bar is the north star's absolute 1e-3.
     for k in ("pred_boxes", "pred_sted", "pred_actioness"):
-        close(o8[k], of[k], 1e-4, "uint8 input " + k, absolute=True)
+        close(o8[k], of[k], 1e-3, "uint8 input " + k, absolute=True)
 
 
 @pytest.mark.gpu
