@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
-    ap.add_argument("--cpu-sample-frames", type=int, default=8,
+    ap.add_argument("--cpu-sample-frames", type=int, default=32,
                     help="frames of the bounded CPU-baseline sample (1 warm-up + 3 repetitions are timed)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
     ap.add_argument("--mma", default="bf16x3p", choices=["f32", "bf16x3", "bf16x6", "bf16x3p"],
