@@ -414,7 +414,11 @@ def main():
                 "mfma_flops_per_algorithmic_flop": mult,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
-        roof["traffic"] = _pmc_traffic(dom, args.mma)
+        tr = _pmc_traffic(dom, args.mma)
+        # `traffic`: HBM bytes per launch of the dominant kernel family (PMC FETCH_SIZE / WRITE_SIZE passes, see the
+        # detail entry for the split and the source file); `achieved`'s counterpart in bytes: algorithmic operand bytes
+        roof["traffic"] = int(tr["MB_per_launch"] * 1e6) if tr else None
+        roof["traffic_detail"] = tr
         roof["mfma_util"] = _pmc_mfma_util()
         mm = sum(v["flop"] for v in agg.values())
         mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)

@@ -2,9 +2,8 @@
 
 The product path has exactly one backend: the HIP library built for gfx950.
 If it is missing, loading fails loudly — there is no CPU or PyTorch fallback.
-(`_use_library_for_testing` lets the CPU test-suite inject the host SIMT
-emulator build of the *same* kernel sources, tests/emu/; nothing in the
-package calls it.)
+(The CPU test-suite binds the host SIMT emulator build of the *same* kernel sources
+from its own side — tests/backends.py::use_emu — nothing in the package does.)
 """
 from __future__ import annotations
 
@@ -114,13 +113,6 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
                 "(hipcc --offload-arch=gfx950). stcat_amd has no CPU/PyTorch fallback.")
         _lib = _bind(ctypes.CDLL(path))
     return _lib
-
-
-def _use_library_for_testing(path: str) -> None:
-    """TEST HOOK: bind the host-emulator build of the kernels (CPU tensors)."""
-    global _lib, _backend
-    _lib = _bind(ctypes.CDLL(path))
-    _backend = "emu"
 
 
 def backend() -> str:

@@ -37,7 +37,10 @@ def use_emu():
     _build_emu()
     if _emu_state["error"]:
         pytest.skip("host emulator build failed: " + _emu_state["error"])
-    L._use_library_for_testing(EMU_SO)
+    # bind the emulator build in place of libstcat_hip.so (test-side only: the package has no such switch)
+    import ctypes
+    L._lib = L._bind(ctypes.CDLL(EMU_SO))
+    L._backend = "emu"
     return torch.device("cpu")
 
 
