@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the process to the GPU's NUMA node")
+    ap.add_argument("--no-auto-graph", action="store_true",
+                    help="N = 1: do not re-measure with the whole-step hipGraph when the eager run turns out host-bound")
     ap.add_argument("--cpu-sample-frames", type=int, default=32,
                     help="frames of the bounded CPU-baseline sample (1 warm-up + 3 repetitions are timed)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
@@ -513,8 +515,12 @@ def main():
         f32_host = torch.empty(T, 3, res, res, dtype=torch.float32).pin_memory()
         loader = {"h2d_MB_uint8": round(u8_host.numel() / 1e6, 1), "h2d_MB_fp32": round(f32_host.numel() * 4 / 1e6, 1)}
         for key, host in (("uint8", u8_host), ("fp32", f32_host)):
+            # a resident device buffer per input form, refilled by an async copy each step (what a loader does; a fresh
+            # `host.to(dev)` per step would hand the allocator a 154 MB block that several streams still hold)
+            dev_buf = torch.empty(host.shape, dtype=host.dtype, device=dev)
+
             def run_once():
-                dev_frames = host.to(dev, non_blocking=True)
+                dev_frames = dev_buf.copy_(host, non_blocking=True)
                 reducer.zero_grad()
                 ops.dropout_begin_step(dev)
                 arena.reset()
@@ -566,6 +572,33 @@ def main():
             "kernels": kernels,
             "gemm_shapes": gemm_shapes,
         }
+    # Launch mode, N = 1.  Eager launching needs ~26-31 ms of host time per step — invisible behind a
+    # 60 ms GPU step on a quiet host, but the pool's hosts are shared: when this process lands on a slow / contended
+    # core the same step becomes HOST-bound (77-100 ms measured, enqueue time == step time).  Replaying the step as
+    # one hipGraph costs the host a third of that, at the price of the two-stream overlaps (66 ms): when, and only
+    # when, the eager run was host-bound, the same K steps are measured again through the captured graph in a fresh
+    # process (capture needs gradient accumulators that never ran on the default stream) and the faster of the two
+    # is reported, with both on record.
+    if (rank == 0 and world == 1 and not args.graph and not args.no_auto_graph and not force_comm
+            and host_s >= 0.97 * elapsed):
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph", "--no-auto-graph", "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--config", args.config, "--mma", args.mma, "--no-cpu-baseline", "--no-exact",
+               "--no-optim", "--no-profile"] + (["--eval-mode"] if args.eval_mode else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            line["launch_modes"] = {"eager_ms_per_step": line["ms_per_step"], "graph_ms_per_step": child["ms_per_step"],
+                                    "eager_host_enqueue_ms_per_step": line["host_enqueue_ms_per_step"],
+                                    "note": "the eager run was host-bound on this host (enqueue time >= 97 % of the step): "
+                                            "re-measured as one hipGraph per step; the faster mode is the reported value"}
+            if child["ms_per_step"] < line["ms_per_step"]:
+                for k in ("value", "ms_per_step", "host_enqueue_ms_per_step", "host_cpu_ms_per_step"):
+                    line[k] = child[k]
+                line["config"]["launch"] = "one hipGraph per step (eager launch was host-bound here)"
+        except Exception as e:  # noqa: BLE001 — the eager measurement stands
+            line["launch_modes"] = {"note": f"graph re-measurement failed: {type(e).__name__}: {e}"[:300]}
+
     # The JSON line must be the LAST thing on stdout.  RCCL writes a version banner through C stdio, which is
     # block-buffered when stdout is a pipe and would otherwise be flushed at process exit, AFTER the line: flush
     # it on every rank, tear the process group down, and only then print.

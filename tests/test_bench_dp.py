@@ -60,3 +60,21 @@ def test_bench_graph_option_still_runs():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     assert d["value"] > 0 and d["config"]["launch"] == "one hipGraph per step"
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_the_graph_when_eager_is_host_bound():
+    """At C1 (T = 8, 224 px) the GPU work is a fraction of the host's enqueue time, so the eager run IS host-bound: the
+    bench must notice (enqueue >= 97 % of the step), re-measure the same steps as one hipGraph per step in a fresh
+    process, put both on record and report the faster one — the safety net for a contended host at C3."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--config", "C1",
+           "--no-cpu-baseline", "--no-exact", "--no-optim", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    lm = d.get("launch_modes")
+    assert lm and "graph_ms_per_step" in lm, d.get("launch_modes")
+    assert d["ms_per_step"] <= lm["eager_ms_per_step"] + 1e-9
+    assert d["ms_per_step"] == min(lm["eager_ms_per_step"], lm["graph_ms_per_step"])

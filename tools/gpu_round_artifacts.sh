@@ -19,7 +19,7 @@ P='import json,sys; d=json.loads(sys.stdin.readline()); print({k:d.get(k) for k 
   STCAT_FORCE_COMM=1 timeout 300 $B --steps 10 --warmup 3 --no-profile 2>&1 | tail -1 | python -c "$P"
   STCAT_FORCE_COMM=1 timeout 300 $B --steps 10 --warmup 3 --no-profile --roberta-dummy 2>&1 | tail -1 | python -c "$P"
   STCAT_NO_FORK=1 timeout 300 $B --steps 10 --warmup 3 --no-profile 2>&1 | tail -1 | python -c "$P"
-  timeout 300 $B --steps 10 --warmup 3 --no-profile --config C1 2>&1 | tail -1 | python -c "$P"
+  timeout 300 $B --steps 10 --warmup 3 --no-profile --no-auto-graph --config C1 2>&1 | tail -1 | python -c "$P"
 } > $O/bench_variants.log 2>&1; cat $O/bench_variants.log
 timeout 300 python tools/host_profile.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.log
 timeout 300 python tools/phase_times.py 2>&1 | grep -v amdgpu.ids | tail -6 >> $O/host_profile.log; tail -6 $O/host_profile.log
