@@ -529,8 +529,8 @@ def main():
                 total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
                 total.backward()
                 reducer.finish()
-            run_once()
-            run_once()
+            for _ in range(5):   # (freshly pinned memory: the first uploads are slow — measured 76 ms vs 61.6 ms steps)
+                run_once()
             fence()
             t1 = time.perf_counter()
             for _ in range(5):
