@@ -309,33 +309,57 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     ms[e] = p.mscale ? p.mscale[n + e] : 1.f;
     s2[e] = p.c2scale ? p.c2scale[n + e] : 1.f;
   }
-  STCAT_UNROLL
-  for (int tm = 0; tm < TM; ++tm) {
+  // The epilogue's global operands — residual planes and the ReLU bit mask — of a 32-row block are requested BEFORE
+  // the block goes through LDS, and those of block tm + 1 before block tm is processed: the K <= 512 layers are bound
+  // by exactly these loads (one HBM round trip per pass otherwise: 4-16 serial round trips per tile).
+  constexpr int NPS = 32 / RPP;
+  struct Pre { bf16x8 rh[NPS], rl[NPS]; unsigned bits[NPS]; int m[NPS]; };
+  Pre pre[2];
+  auto prefetch = [&](Pre& q, int tm) {
     STCAT_UNROLL
-    for (int tn = 0; tn < TN; ++tn) {
-      STCAT_UNROLL
-      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDE + tn * 32 + l31] = acc[tm][tn][r];
-    }
-    STCAT_WAVE_LDS_FENCE();
-    STCAT_UNROLL
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
-      const int row = ps * RPP + erow;
-      const int mrow = m0 + wm * TM * 32 + tm * 32 + row;
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int mrow = m0 + wm * TM * 32 + tm * 32 + ps * RPP + erow;
       int m = mrow;                      // output row = pixel index
       if (p.par && mrow < Mc) {
         const int nb = mrow / (OHc * OWc), rem = mrow - nb * OHc * OWc, oh = rem / OWc, ow = rem - oh * OWc;
         m = (nb * g.OH + 2 * oh + py) * g.OW + 2 * ow + px;
       }
+      q.m[ps] = m;
+      if (mrow < Mc && !(p.debug & 2)) {
+        if (p.Rh) {
+          q.rh[ps] = *reinterpret_cast<const bf16x8*>(p.Rh + (long)m * p.ldr + n);
+          q.rl[ps] = *reinterpret_cast<const bf16x8*>(p.Rl + (long)m * p.ldr + n);
+        }
+        if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
+      }
+    }
+  };
+  constexpr bool DB = !(BM == 256 && BN == 256);   // (the 256 x 256 tile has no registers left for the second set)
+  if (DB) prefetch(pre[0], 0);
+  STCAT_UNROLL
+  for (int tm = 0; tm < TM; ++tm) {
+    if (!DB) prefetch(pre[0], tm);
+    STCAT_UNROLL
+    for (int tn = 0; tn < TN; ++tn) {
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) ew[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDE + tn * 32 + l31] = acc[tm][tn][r];
+    }
+    if (DB && tm + 1 < TM) prefetch(pre[(tm + 1) & 1], tm + 1);
+    const Pre& cur = pre[DB ? (tm & 1) : 0];
+    STCAT_WAVE_LDS_FENCE();
+    STCAT_UNROLL
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int row = ps * RPP + erow;
+      const int mrow = m0 + wm * TM * 32 + tm * 32 + row;
+      const int m = cur.m[ps];
       const float4 v0 = stcat_ld4(&ew[row * LDE + ecol]), v1 = stcat_ld4(&ew[row * LDE + ecol + 4]);
       float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       if (mrow < Mc && !((p.debug & 2) && x[0] != 12345.f)) {
         STCAT_UNROLL
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
         if (p.Rh) {
-          float rr[8];
-          stcat_join8(p.Rh + (long)m * p.ldr + n, p.Rl + (long)m * p.ldr + n, rr);
           STCAT_UNROLL
-          for (int e = 0; e < 8; ++e) x[e] += rr[e];
+          for (int e = 0; e < 8; ++e) x[e] += (float)cur.rh[ps][e] + (float)cur.rl[ps][e];
         } else if (F32 && p.Rf) {
           const float4 r0 = stcat_ld4(p.Rf + (long)m * p.ldr + n), r1 = stcat_ld4(p.Rf + (long)m * p.ldr + n + 4);
           x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
@@ -345,7 +369,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
         if (p.Mi) {
-          const unsigned bits = p.Mi[((long)m * p.ldc + n) >> 3];
+          const unsigned bits = cur.bits[ps];
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = ((bits >> e) & 1u) ? x[e] * ms[e] : 0.f;
         } else if (p.Yh) {
