@@ -231,12 +231,15 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
         if (!F32) stcat_glds16(dBl_, base_ + 2 * PLANE_A + PLANE_B + i * 8192, b_voff[i], soB_);        \
       }                                                                                                 \
     }                                                                                                   \
-    ++kl; l_c0 += BK;                                                                                   \
-    if (l_c0 == g.C) {                                                                                  \
-      l_c0 = 0; l_kw += kstep;                                                                          \
-      if (l_kw >= g.KW) { l_kw = kw0; l_kh += kstep; }                                                  \
-      l_tap = l_kh * g.KW + l_kw;                                                                       \
+    /* K order: channel chunk OUTER, filter tap INNER — the 9 taps of a 3x3 filter re-read the same pixels shifted  \
+       by one row / column; walked back to back on one 32-channel chunk they find them in L2 (a tile's chunk is       \
+       ~36 KB; tap-outer order re-fetched the tile's whole 230 KB input per tap: 9x the distinct bytes, PMC) */        \
+    ++kl; l_kw += kstep;                                                                                \
+    if (l_kw >= g.KW) {                                                                                 \
+      l_kw = kw0; l_kh += kstep;                                                                        \
+      if (l_kh >= g.KH) { l_kh = kh0; l_c0 += BK; }                                                     \
     }                                                                                                   \
+    l_tap = l_kh * g.KW + l_kw;                                                                         \
   }
 
   // ---- fragment addressing: lane -> row l31 of its tile, k-step ks -> chunk (2 ks + hi) ^ ((row >> 2) & 3)
