@@ -434,6 +434,11 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   const int BN = (p.g.C % 256 == 0 && g_pl_force != 3 && !(BM == 128 && g_pl_force == 3)) ? 256 : 128;
   const int tiles = (rows / BM) * (cols / BN);
   int nsplit = 256 / tiles;                 // one round of one workgroup per CU
+  // The tap tiles of a slice share dY and the (shifted) X pixels through their XCD's 4 MB L2 — if the slice fits.  At
+  // layer2 (200704 pixels, 128 channels) a 1/28 slice is 7.3 MB of operands and nothing is shared (PMC: 1.65 GB read
+  // per launch, the sum of all workgroups' private reads); two rounds of half-size slices: 0.256 -> 0.173 ms.
+  // (Single-tap layers have no such sharing and only pay the extra atomics: 0.131 -> 0.152 ms, so they keep one round.)
+  if (p.g.KH * p.g.KW > 1 && nsplit >= 1 && (double)cdiv(red, nsplit) * (rows + p.g.C) * 4.0 > 4.5e6) nsplit *= 2;
   const int max_split = cdiv(red, 512);     // at least 16 K-tiles per workgroup
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
