@@ -438,7 +438,8 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   // layer2 (200704 pixels, 128 channels) a 1/28 slice is 7.3 MB of operands and nothing is shared (PMC: 1.65 GB read
   // per launch, the sum of all workgroups' private reads); two rounds of half-size slices: 0.256 -> 0.173 ms.
   // (Single-tap layers have no such sharing and only pay the extra atomics: 0.131 -> 0.152 ms, so they keep one round.)
-  if (p.g.KH * p.g.KW > 1 && nsplit >= 1 && (double)cdiv(red, nsplit) * (rows + p.g.C) * 4.0 > 4.5e6) nsplit *= 2;
+  // (Only when a slice's tiles sit on ONE XCD, <= 32 of them: layer4's 36 tiles per slice span XCDs and lose, 0.173 -> 0.212.)
+  if (p.g.KH * p.g.KW > 1 && tiles <= 32 && nsplit >= 1 && (double)cdiv(red, nsplit) * (rows + p.g.C) * 4.0 > 4.5e6) nsplit *= 2;
   const int max_split = cdiv(red, 512);     // at least 16 K-tiles per workgroup
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
