@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=32,
                     help="frames of the bounded CPU-baseline sample (1 warm-up + 3 repetitions are timed)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle baseline")
-    ap.add_argument("--mma", default="bf16x3p", choices=["f32", "bf16x3", "bf16x6", "bf16x3p"],
+    ap.add_argument("--mma", default="bf16x3p", choices=["f32", "bf16x3", "bf16x6", "bf16x3p", "bf16x6p"],
                     help="arithmetic of the conv/Linear GEMM family (fp32 tensors in HBM in every mode); bf16x3 is the "
                          "split-product parity mode of SURVEY.md §7 hard part 3 (meets the 1e-3 / bit-exact-span bars)")
     ap.add_argument("--eval-mode", action="store_true",
@@ -392,7 +392,7 @@ def main():
         # dominant KERNEL: in the split-bf16 modes the conv forward and the conv data gradient (pre-transposed
         # weights) are the same device kernel, igemm_bs_fwd_kernel<128,128,NS> — price them together
         fam = dict(agg)
-        if args.mma == "bf16x3p" and "stcat_pl_conv_fwd" in agg and "stcat_pl_conv_dgrad" in agg:
+        if args.mma in ("bf16x3p", "bf16x6p") and "stcat_pl_conv_fwd" in agg and "stcat_pl_conv_dgrad" in agg:
             a, b = agg["stcat_pl_conv_fwd"], agg["stcat_pl_conv_dgrad"]
             fam = {k: v for k, v in agg.items() if k not in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad")}
             fam["igemm_pl_fwd_kernel (stcat_pl_conv_fwd + stcat_pl_conv_dgrad)"] = {
@@ -408,7 +408,7 @@ def main():
         # `achieved` = ALGORITHMIC flops (2 x MAC of the contraction) / launch time and `frac` = that
         # over the peak of the pipe the kernel runs on.  A split-bf16 product issues 3 (6) bf16 MFMA flops per
         # algorithmic flop: the issued rate — what the matrix pipe actually executes — is reported beside it.
-        mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6, "bf16x3p": 3}[args.mma]
+        mult = {"f32": 1, "bf16x3": 3, "bf16x6": 6, "bf16x3p": 3, "bf16x6p": 6}[args.mma]
         peak = PEAK_TFLOPS_F32_MFMA if args.mma == "f32" else PEAK_TFLOPS_BF16_MFMA
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
@@ -437,8 +437,9 @@ def main():
         other_modes = {}
         notes = {"f32": "f32 (v_mfma_f32_32x32x2_f32, exact products)", "bf16x6": "fp32 tensors, 6 bf16 cross terms (fp32-class)",
                  "bf16x3": "fp32 tensors, 3 bf16 cross terms, operands split in-kernel",
-                 "bf16x3p": "3 bf16 cross terms, backbone tensors pre-split into bf16 planes"}
-        for mode in ("f32", "bf16x6", "bf16x3", "bf16x3p"):
+                 "bf16x3p": "3 bf16 cross terms, backbone tensors pre-split into two bf16 planes (16 significand bits)",
+                 "bf16x6p": "6 bf16 cross terms, backbone tensors pre-split into three bf16 planes (= fp32 exactly)"}
+        for mode in ("f32", "bf16x6", "bf16x3", "bf16x3p", "bf16x6p"):
             if mode == args.mma:
                 continue
             _lib.set_mma_mode(mode)
@@ -557,7 +558,10 @@ def main():
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",
                       "bf16x6": "f32 tensors, bf16x6 split products, f32 accumulate",
                       "bf16x3p": "bf16x3 split products, f32 accumulate; backbone tensors stored as bf16 hi+lo planes "
-                                 "(16 significand bits), everything else f32"}[args.mma], "data": "synthetic",
+                                 "(16 significand bits), everything else f32",
+                      "bf16x6p": "f32-class: bf16x6 split products (six cross terms, ~2^-24), f32 accumulate; backbone "
+                                 "tensors stored as three bf16 planes (hi+mid+lo = the f32 value exactly), everything "
+                                 "else f32, attention on the f32 matrix pipe"}[args.mma], "data": "synthetic",
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",

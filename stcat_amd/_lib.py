@@ -119,20 +119,34 @@ def backend() -> str:
     return _backend
 
 
-MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "bf16x3p": 4}
+MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "bf16x3p": 4, "bf16x6p": 5}
+PLANE_MODES = {"bf16x3p": 2, "bf16x6p": 3}   # mode -> bf16 planes per backbone tensor
+_mode_cache = None
 
 
 def set_mma_mode(mode: str) -> None:
     """Arithmetic of the conv / Linear GEMM family: 'f32' (exact fp32 MFMA), 'bf16x3' or 'bf16x6'
     (fp32 operands split into bf16 pieces on the bf16 matrix pipe, fp32 accumulate), or 'bf16x3p': the bf16x3
     arithmetic with the backbone's activations / gradients / weights kept PRE-SPLIT as bf16 hi/lo planes in HBM
-    (csrc/igemm_pl.h: LDS-DMA staged 256-wide tiles); all other GEMMs run as 'bf16x3'."""
+    (csrc/igemm_pl.h: LDS-DMA staged 256-wide tiles); all other GEMMs run as 'bf16x3'.  'bf16x6p' is the fp32-class
+    form of that layout: THREE bf16 planes per tensor (hi + mid + lo = the fp32 value exactly), six cross terms per
+    product; all other GEMMs run as 'bf16x6' and attention on the fp32 matrix pipe."""
+    global _mode_cache
     call("stcat_set_mma_mode", MMA_MODES[mode])
+    _mode_cache = mode
 
 
 def get_mma_mode() -> str:
-    code = load().stcat_get_mma_mode()
-    return {v: k for k, v in MMA_MODES.items()}[code]
+    global _mode_cache
+    if _mode_cache is None:
+        code = load().stcat_get_mma_mode()
+        _mode_cache = {v: k for k, v in MMA_MODES.items()}[code]
+    return _mode_cache
+
+
+def plane_count() -> int:
+    """bf16 planes per backbone tensor in the current mode (0: the mode keeps fp32 tensors)"""
+    return PLANE_MODES.get(get_mma_mode(), 0)
 
 
 def _ptr(t):

@@ -330,7 +330,7 @@ class Backbone(nn.Module):
         weights = self._plist  # same order as body.parameters(): the backward returns one gradient per entry
         if weights is None or len(weights) == 0:
             weights = self._plist = [p for p in self.body.parameters()]
-        if ops.L.get_mma_mode() == "bf16x3p":
+        if ops.L.plane_count():
             return _BackboneFnPl.apply(frames, self.body, *weights)
         return _BackboneFn.apply(frames, self.body, *weights)
 

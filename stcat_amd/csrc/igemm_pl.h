@@ -70,6 +70,51 @@ static __device__ __forceinline__ void stcat_split8(const float (&v)[8], bf16x8&
     l[e] = (__bf16)(v[e] - (float)hh);
   }
 }
+// Plane sets.  NP = 2 (mma mode bf16x3p): x ~ p0 + p1, 16 significand bits.  NP = 3 (mma mode bf16x6p): x = p0 + p1 + p2
+// EXACTLY (p0 = bf16(x), p1 = bf16(x - p0), p2 = x - p0 - p1: 8 + 8 + 8 significand bits, every residual is exact in
+// fp32), so the tensors in HBM carry all of fp32; the contraction keeps the six cross terms down to 2^-16 relative
+// (p0 q0, p0 q1, p1 q0, p1 q1, p0 q2, p2 q0) and drops the three of relative size <= 2^-24 — fp32-class products.
+// The planes of one tensor lie at EQUAL spacing in one allocation: callers pass the first two pointers, the third
+// is l + (l - h).
+static __device__ __forceinline__ const __bf16* stcat_plane(const __bf16* h, const __bf16* l, int i) {
+  return i == 0 ? h : (i == 1 ? l : l + (l - h));
+}
+static __device__ __forceinline__ __bf16* stcat_plane(__bf16* h, __bf16* l, int i) {
+  return i == 0 ? h : (i == 1 ? l : l + (l - h));
+}
+template <int NP>
+static __device__ __forceinline__ void stcat_split8n(const float (&v)[8], bf16x8 (&o)[NP]) {
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    float r = v[e];
+    STCAT_UNROLL
+    for (int i = 0; i < NP; ++i) {
+      const __bf16 q = (__bf16)r;
+      o[i][e] = q;
+      r -= (float)q;
+    }
+  }
+}
+// value of element e of a plane set held in registers (small pieces first: the sum is exact for NP = 3)
+template <int NP>
+static __device__ __forceinline__ float stcat_join1(const bf16x8 (&o)[NP], int e) {
+  float r = (float)o[NP - 1][e];
+  STCAT_UNROLL
+  for (int i = NP - 2; i >= 0; --i) r += (float)o[i][e];
+  return r;
+}
+// cross terms of the split contraction, smallest first: (index of the A piece, index of the B piece)
+template <int NP> struct PlProd;
+template <> struct PlProd<2> {
+  static constexpr int N = 3;
+  static __device__ __forceinline__ constexpr int a(int i) { return i == 0 ? 1 : 0; }
+  static __device__ __forceinline__ constexpr int b(int i) { return i == 1 ? 1 : 0; }
+};
+template <> struct PlProd<3> {
+  static constexpr int N = 6;   // (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+  static __device__ __forceinline__ constexpr int a(int i) { return i == 0 ? 2 : ((i == 2 || i == 3) ? 1 : 0); }
+  static __device__ __forceinline__ constexpr int b(int i) { return i == 1 ? 2 : ((i == 2 || i == 4) ? 1 : 0); }
+};
 // float e (0..3) of a 16-byte fragment register
 static __device__ __forceinline__ float stcat_f4(const bf16x8& v, int e) {
   const float4 f = __builtin_bit_cast(float4, v);
@@ -92,22 +137,17 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
     }                                                         \
   }
 
-// 3 MFMA groups of one k-step (16 reduction terms); split terms outermost so consecutive MFMAs hit different accumulators
+// the MFMA groups of one k-step (16 reduction terms): 3 (NP = 2) or 6 (NP = 3) cross terms, term outermost so that
+// consecutive MFMAs hit different accumulators
 #define STCAT_PL_MMA(F)                                                                                 \
   STCAT_UNROLL                                                                                          \
-  for (int tm = 0; tm < TM; ++tm) {                                                                     \
+  for (int pr_ = 0; pr_ < PlProd<NP>::N; ++pr_) {                                                       \
     STCAT_UNROLL                                                                                        \
-    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.al[tm], F.bh[tn], acc[tm][tn]); \
-  }                                                                                                     \
-  STCAT_UNROLL                                                                                          \
-  for (int tm = 0; tm < TM; ++tm) {                                                                     \
-    STCAT_UNROLL                                                                                        \
-    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.ah[tm], F.bl[tn], acc[tm][tn]); \
-  }                                                                                                     \
-  STCAT_UNROLL                                                                                          \
-  for (int tm = 0; tm < TM; ++tm) {                                                                     \
-    STCAT_UNROLL                                                                                        \
-    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.ah[tm], F.bh[tn], acc[tm][tn]); \
+    for (int tm = 0; tm < TM; ++tm) {                                                                   \
+      STCAT_UNROLL                                                                                      \
+      for (int tn = 0; tn < TN; ++tn)                                                                   \
+        acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.a[PlProd<NP>::a(pr_)][tm], F.b[PlProd<NP>::b(pr_)][tn], acc[tm][tn]); \
+    }                                                                                                   \
   }
 
 // exact-fp32 form: a 16-byte fragment is FOUR fp32 reduction terms of the lane's row (the lane pair (l31, hi) covers 8
@@ -120,7 +160,7 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
     for (int tm = 0; tm < TM; ++tm) {                                                                   \
       STCAT_UNROLL                                                                                      \
       for (int tn = 0; tn < TN; ++tn)                                                                   \
-        acc[tm][tn] = STCAT_MFMA_32x32x2(stcat_f4(F.ah[tm], e), stcat_f4(F.bh[tn], e), acc[tm][tn]);    \
+        acc[tm][tn] = STCAT_MFMA_32x32x2(stcat_f4(F.a[0][tm], e), stcat_f4(F.b[0][tn], e), acc[tm][tn]);    \
     }                                                                                                   \
   }
 
@@ -140,12 +180,15 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
 // forward / data gradient:  C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (tap, c), c fastest
 // 8 waves as WM x WN, wave tile (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32 x 32.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool F32 = false>
+template <int BM, int BN, int WM, int WN, bool F32 = false, int NP = 2>
 __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   static_assert(WM * WN == 8, "8 waves");
+  static_assert(!(F32 && NP != 2), "the exact-fp32 form keeps the two-plane LDS layout");
   constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NPL = F32 ? 1 : NP;                              // planes actually staged
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;            // bytes: rows x 64 B
-  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;               // Ah, Al, Bh, Bl
+  constexpr int STAGE = NP * (PLANE_A + PLANE_B);                // A planes, then B planes
+  static_assert(2 * STAGE <= 160 * 1024, "two stages fit the CU's LDS");
   constexpr int QA = BM / 16, QB = BN / 16;                      // 1-KiB DMA pieces (16 rows) per plane
   constexpr int RQA = (QA + 7) / 8, RQB = (QB + 7) / 8;          // pieces per wave
   constexpr int LDE = TN * 32 + 4;                               // epilogue block: 32 rows x (TN*32) fp32, padded
@@ -200,6 +243,8 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
     const int q = wave + 8 * i, r = q * 16 + (lane >> 2);
     b_voff[i] = q < QB ? (unsigned)(((n0 + r) * p.ldb) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16) : STCAT_BUF_OOB;
   }
+  const __bf16* Ap[3] = {p.Ah, p.Al, stcat_plane(p.Ah, p.Al, 2)};
+  const __bf16* Bp[3] = {p.Bh, p.Bl, stcat_plane(p.Bh, p.Bl, 2)};
   // load cursor: K-tile kl = (tap (kh, kw), channel offset c0); advances one tile per stage_load.  Tiles past the end
   // go through zero-length descriptors (zero fill into a stage nobody reads): the loop body stays branch-free, which
   // keeps the compiler's wait counts exact.
@@ -208,8 +253,12 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
 #define STCAT_PL_STAGE_LOAD(ST)                                                                         \
   {                                                                                                     \
     const bool live_ = kl < nk;                                                                         \
-    const stcat_buf_t dAh_ = stcat_make_buf(p.Ah, live_ ? p.a_bytes : 0u), dAl_ = stcat_make_buf(p.Al, live_ ? p.a_bytes : 0u); \
-    const stcat_buf_t dBh_ = stcat_make_buf(p.Bh, live_ ? p.b_bytes : 0u), dBl_ = stcat_make_buf(p.Bl, live_ ? p.b_bytes : 0u); \
+    stcat_buf_t dA_[NPL], dB_[NPL];                                                                     \
+    STCAT_UNROLL                                                                                        \
+    for (int pi_ = 0; pi_ < NPL; ++pi_) {                                                               \
+      dA_[pi_] = stcat_make_buf(Ap[pi_], live_ ? p.a_bytes : 0u);                                       \
+      dB_[pi_] = stcat_make_buf(Bp[pi_], live_ ? p.b_bytes : 0u);                                       \
+    }                                                                                                   \
     const unsigned soA_ = (unsigned)l_c0 * 2u, soB_ = ((unsigned)l_tap * p.b_tap_stride + (unsigned)l_c0) * 2u; \
     char* base_ = smem + (ST) * STAGE + wq * 1024;                                                      \
     STCAT_UNROLL                                                                                        \
@@ -220,15 +269,16 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       ok_ = ok_ & ((unsigned)h_ < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);                      \
       const unsigned vo_ = ok_ ? (unsigned)(((a_nb[i] * g.H + h_) * g.W + w_) * g.ld) * 2u + a_c16[i] : STCAT_BUF_OOB; \
       if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
-        stcat_glds16(dAh_, base_ + i * 8192, vo_, soA_);                                                \
-        if (!F32) stcat_glds16(dAl_, base_ + PLANE_A + i * 8192, vo_, soA_);                            \
+        STCAT_UNROLL                                                                                    \
+        for (int pi_ = 0; pi_ < NPL; ++pi_) stcat_glds16(dA_[pi_], base_ + pi_ * PLANE_A + i * 8192, vo_, soA_); \
       }                                                                                                 \
     }                                                                                                   \
     STCAT_UNROLL                                                                                        \
     for (int i = 0; i < RQB; ++i) {                                                                     \
       if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
-        stcat_glds16(dBh_, base_ + 2 * PLANE_A + i * 8192, b_voff[i], soB_);                            \
-        if (!F32) stcat_glds16(dBl_, base_ + 2 * PLANE_A + PLANE_B + i * 8192, b_voff[i], soB_);        \
+        STCAT_UNROLL                                                                                    \
+        for (int pi_ = 0; pi_ < NPL; ++pi_)                                                             \
+          stcat_glds16(dB_[pi_], base_ + NP * PLANE_A + pi_ * PLANE_B + i * 8192, b_voff[i], soB_);     \
       }                                                                                                 \
     }                                                                                                   \
     /* K order: channel chunk OUTER, filter tap INNER — the 9 taps of a 3x3 filter re-read the same pixels shifted  \
@@ -248,24 +298,26 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   for (int ks = 0; ks < 2; ++ks) {
     const int c = ks * 2 + hi, sw = (l31 >> 2) & 3;
     fa_off[ks] = (unsigned)((wm * TM * 32 + l31) * 64 + ((c ^ sw) * 16));
-    fb_off[ks] = (unsigned)(2 * PLANE_A + (wn * TN * 32 + l31) * 64 + ((c ^ sw) * 16));
+    fb_off[ks] = (unsigned)(NP * PLANE_A + (wn * TN * 32 + l31) * 64 + ((c ^ sw) * 16));
   }
-  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  struct Frag { bf16x8 a[NPL][TM], b[NPL][TN]; };
 #define STCAT_PL_READ_FRAG(F, SB, KS)                                                                   \
   STCAT_UNROLL                                                                                          \
   for (int tn = 0; tn < TN; ++tn) {                                                                     \
-    F.bh[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + tn * 2048);                         \
-    if (!F32) F.bl[tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + PLANE_B + tn * 2048);     \
+    STCAT_UNROLL                                                                                        \
+    for (int pi_ = 0; pi_ < NPL; ++pi_)                                                                 \
+      F.b[pi_][tn] = *reinterpret_cast<const bf16x8*>((SB) + fb_off[KS] + pi_ * PLANE_B + tn * 2048);   \
   }                                                                                                     \
   STCAT_UNROLL                                                                                          \
   for (int tm = 0; tm < TM; ++tm) {                                                                     \
-    F.ah[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + tm * 2048);                         \
-    if (!F32) F.al[tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + PLANE_A + tm * 2048);     \
+    STCAT_UNROLL                                                                                        \
+    for (int pi_ = 0; pi_ < NPL; ++pi_)                                                                 \
+      F.a[pi_][tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + pi_ * PLANE_A + tm * 2048);   \
   }
 
   STCAT_PL_ACC_INIT
-  constexpr int NMMA = (F32 ? 4 : 3) * TM * TN, NRD = (F32 ? 1 : 2) * (TM + TN);
-  constexpr int NDMA = (F32 ? 1 : 2) * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  constexpr int NMMA = (F32 ? 4 : PlProd<NP>::N) * TM * TN, NRD = NPL * (TM + TN);
+  constexpr int NDMA = NPL * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
   Frag fa, fb;
   STCAT_PL_STAGE_LOAD(0)
   STCAT_PL_STAGE_LOAD(1)
@@ -316,7 +368,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   // the block goes through LDS, and those of block tm + 1 before block tm is processed: the K <= 512 layers are bound
   // by exactly these loads (one HBM round trip per pass otherwise: 4-16 serial round trips per tile).
   constexpr int NPS = 32 / RPP;
-  struct Pre { bf16x8 rh[NPS], rl[NPS]; unsigned bits[NPS]; int m[NPS]; };
+  struct Pre { bf16x8 r[NPS][NP]; unsigned bits[NPS]; int m[NPS]; };
+  const __bf16* Rp[3] = {p.Rh, p.Rl, stcat_plane(p.Rh, p.Rl, 2)};
+  __bf16* Cp[3] = {p.Ch, p.Cl, stcat_plane(p.Ch, p.Cl, 2)};
+  __bf16* C2p[3] = {p.C2h, p.C2l, stcat_plane(p.C2h, p.C2l, 2)};
   Pre pre[2];
   auto prefetch = [&](Pre& q, int tm) {
     STCAT_UNROLL
@@ -330,14 +385,14 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       q.m[ps] = m;
       if (mrow < Mc && !(p.debug & 2)) {
         if (p.Rh) {
-          q.rh[ps] = *reinterpret_cast<const bf16x8*>(p.Rh + (long)m * p.ldr + n);
-          q.rl[ps] = *reinterpret_cast<const bf16x8*>(p.Rl + (long)m * p.ldr + n);
+          STCAT_UNROLL
+          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = *reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n);
         }
         if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
       }
     }
   };
-  constexpr bool DB = !(BM == 256 && BN == 256);   // (the 256 x 256 tile has no registers left for the second set)
+  constexpr bool DB = !(BM == 256 && BN == 256) && !(NP == 3 && TM * TN >= 4);   // (no registers left for the second set)
   if (DB) prefetch(pre[0], 0);
   STCAT_UNROLL
   for (int tm = 0; tm < TM; ++tm) {
@@ -362,7 +417,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
         if (p.Rh) {
           STCAT_UNROLL
-          for (int e = 0; e < 8; ++e) x[e] += (float)cur.rh[ps][e] + (float)cur.rl[ps][e];
+          for (int e = 0; e < 8; ++e) x[e] += stcat_join1<NP>(cur.r[ps], e);
         } else if (F32 && p.Rf) {
           const float4 r0 = stcat_ld4(p.Rf + (long)m * p.ldr + n), r1 = stcat_ld4(p.Rf + (long)m * p.ldr + n + 4);
           x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
@@ -376,10 +431,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = ((bits >> e) & 1u) ? x[e] * ms[e] : 0.f;
         } else if (p.Yh) {
-          float yy[8];
-          stcat_join8(p.Yh + (long)m * p.ldc + n, p.Yl + (long)m * p.ldc + n, yy);
+          // the sign of y is the sign of its leading plane (the residual planes never flip it; y == 0 <=> p0 == 0)
+          const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(p.Yh + (long)m * p.ldc + n);
           STCAT_UNROLL
-          for (int e = 0; e < 8; ++e) x[e] = yy[e] > 0.f ? x[e] * ms[e] : 0.f;
+          for (int e = 0; e < 8; ++e) x[e] = (float)y0[e] > 0.f ? x[e] * ms[e] : 0.f;
         } else if (F32 && p.Yf) {
           const float4 y0 = stcat_ld4(p.Yf + (long)m * p.ldc + n), y1 = stcat_ld4(p.Yf + (long)m * p.ldc + n + 4);
           const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -393,10 +448,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
           p.Mo[((long)m * p.ldc + n) >> 3] = (unsigned char)bits;
         }
         if (p.Ch) {
-          bf16x8 h8, l8;
-          stcat_split8(x, h8, l8);
-          *reinterpret_cast<bf16x8*>(p.Ch + (long)m * p.ldc + n) = h8;
-          *reinterpret_cast<bf16x8*>(p.Cl + (long)m * p.ldc + n) = l8;
+          bf16x8 o8[NP];
+          stcat_split8n<NP>(x, o8);
+          STCAT_UNROLL
+          for (int pi = 0; pi < NP; ++pi) *reinterpret_cast<bf16x8*>(Cp[pi] + (long)m * p.ldc + n) = o8[pi];
         }
         if (p.Cf) {
           stcat_st4(p.Cf + (long)m * p.ldc + n, make_float4(x[0], x[1], x[2], x[3]));
@@ -409,10 +464,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
         if (p.C2h) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] *= s2[e];
-          bf16x8 h8, l8;
-          stcat_split8(x, h8, l8);
-          *reinterpret_cast<bf16x8*>(p.C2h + (long)m * p.ldc + n) = h8;
-          *reinterpret_cast<bf16x8*>(p.C2l + (long)m * p.ldc + n) = l8;
+          bf16x8 o8[NP];
+          stcat_split8n<NP>(x, o8);
+          STCAT_UNROLL
+          for (int pi = 0; pi < NP; ++pi) *reinterpret_cast<bf16x8*>(C2p[pi] + (long)m * p.ldc + n) = o8[pi];
         }
       }
     }
@@ -428,14 +483,15 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
 // bytes; its 64-byte segments are XOR-ed with (k & 3) inside each 256-byte group, so the four k-rows that one
 // transposing read touches sit in four different bank quarters.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NP = 2>
 __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(BM % 128 == 0 && BN % 128 == 0, "a k-row is a whole number of 256-byte groups");
   constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int ROWA = BM * 2, ROWB = BN * 2;                    // bytes per k-row
   constexpr int PLANE_A = BK * ROWA, PLANE_B = BK * ROWB;
-  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  constexpr int STAGE = NP * (PLANE_A + PLANE_B);
+  static_assert(2 * STAGE <= 160 * 1024, "two stages fit the CU's LDS");
   constexpr int QA = PLANE_A / 1024, QB = PLANE_B / 1024;        // 1-KiB DMA pieces per plane
   constexpr int RQA = (QA + 7) / 8, RQB = (QB + 7) / 8;
   constexpr int LA = ROWA / 16, LB = ROWB / 16;                  // lanes (16-byte chunks) per k-row
@@ -477,8 +533,12 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
     b_kr[i] = q < QB ? kr : -1;
     b_col[i] = (unsigned)((ci0 * 2) + ((cp ^ ((kr & 3) << 2)) * 16));
   }
-  const stcat_buf_t dAh = stcat_make_buf(p.Ah, p.a_bytes), dAl = stcat_make_buf(p.Al, p.a_bytes);
-  const stcat_buf_t dBh = stcat_make_buf(p.Bh, p.b_bytes), dBl = stcat_make_buf(p.Bl, p.b_bytes);
+  stcat_buf_t dA[NP], dB[NP];
+  STCAT_UNROLL
+  for (int pi = 0; pi < NP; ++pi) {
+    dA[pi] = stcat_make_buf(stcat_plane(p.Ah, p.Al, pi), p.a_bytes);
+    dB[pi] = stcat_make_buf(stcat_plane(p.Bh, p.Bl, pi), p.b_bytes);
+  }
   int kl = 0;
 #define STCAT_PLW_STAGE_LOAD(ST)                                                                        \
   {                                                                                                     \
@@ -489,8 +549,8 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       const int m_ = mb_ + a_kr[i];                                                                     \
       const unsigned vo_ = (a_kr[i] >= 0 && m_ < red1) ? (unsigned)(m_ * p.ldb) * 2u + a_col[i] : STCAT_BUF_OOB; \
       if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
-        stcat_glds16(dAh, base_ + i * 8192, vo_, 0u);                                                   \
-        stcat_glds16(dAl, base_ + PLANE_A + i * 8192, vo_, 0u);                                         \
+        STCAT_UNROLL                                                                                    \
+        for (int pi_ = 0; pi_ < NP; ++pi_) stcat_glds16(dA[pi_], base_ + pi_ * PLANE_A + i * 8192, vo_, 0u); \
       }                                                                                                 \
     }                                                                                                   \
     STCAT_UNROLL                                                                                        \
@@ -502,8 +562,9 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       const bool ok_ = (b_kr[i] >= 0) & (m_ < red1) & ((unsigned)h_ < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W); \
       const unsigned vo_ = ok_ ? (unsigned)(((nb_ * g.H + h_) * g.W + w_) * g.ld) * 2u + b_col[i] : STCAT_BUF_OOB; \
       if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
-        stcat_glds16(dBh, base_ + 2 * PLANE_A + i * 8192, vo_, 0u);                                     \
-        stcat_glds16(dBl, base_ + 2 * PLANE_A + PLANE_B + i * 8192, vo_, 0u);                           \
+        STCAT_UNROLL                                                                                    \
+        for (int pi_ = 0; pi_ < NP; ++pi_)                                                              \
+          stcat_glds16(dB[pi_], base_ + NP * PLANE_A + pi_ * PLANE_B + i * 8192, vo_, 0u);              \
       }                                                                                                 \
     }                                                                                                   \
     ++kl;                                                                                               \
@@ -516,13 +577,13 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
   // (wave's first segment + T) ^ (pl >> 2).
   const int pl = lane & 15, gq = (lane >> 4) & 1, kx = pl >> 2;
   const unsigned ta_lane = (unsigned)((hi * 8 + kx) * ROWA + gq * 32 + (pl & 3) * 8);
-  const unsigned tb_lane = (unsigned)(2 * PLANE_A + (hi * 8 + kx) * ROWB + gq * 32 + (pl & 3) * 8);
+  const unsigned tb_lane = (unsigned)(NP * PLANE_A + (hi * 8 + kx) * ROWB + gq * 32 + (pl & 3) * 8);
   unsigned ta_seg[TM], tb_seg[TN];
   STCAT_UNROLL
   for (int tm = 0; tm < TM; ++tm) ta_seg[tm] = (unsigned)(((wm * TM + tm) ^ kx) << 6);
   STCAT_UNROLL
   for (int tn = 0; tn < TN; ++tn) tb_seg[tn] = (unsigned)(((wn * TN + tn) ^ kx) << 6);
-  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  struct Frag { bf16x8 a[NP][TM], b[NP][TN]; };
 #define STCAT_PLW_TR8(DST, ADDR, ROW, KS)                                                               \
   {                                                                                                     \
     const bf16x4 lo4_ = stcat_lds_tr4(reinterpret_cast<const __bf16*>((ADDR) + ((KS) * 16) * (ROW)));   \
@@ -533,18 +594,20 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
 #define STCAT_PLW_READ_FRAG(F, SB, KS)                                                                  \
   STCAT_UNROLL                                                                                          \
   for (int tn = 0; tn < TN; ++tn) {                                                                     \
-    STCAT_PLW_TR8(F.bh[tn], (SB) + tb_lane + tb_seg[tn], ROWB, KS)                                      \
-    STCAT_PLW_TR8(F.bl[tn], (SB) + tb_lane + tb_seg[tn] + PLANE_B, ROWB, KS)                            \
+    STCAT_UNROLL                                                                                        \
+    for (int pi_ = 0; pi_ < NP; ++pi_)                                                                  \
+      STCAT_PLW_TR8(F.b[pi_][tn], (SB) + tb_lane + tb_seg[tn] + pi_ * PLANE_B, ROWB, KS)                \
   }                                                                                                     \
   STCAT_UNROLL                                                                                          \
   for (int tm = 0; tm < TM; ++tm) {                                                                     \
-    STCAT_PLW_TR8(F.ah[tm], (SB) + ta_lane + ta_seg[tm], ROWA, KS)                                      \
-    STCAT_PLW_TR8(F.al[tm], (SB) + ta_lane + ta_seg[tm] + PLANE_A, ROWA, KS)                            \
+    STCAT_UNROLL                                                                                        \
+    for (int pi_ = 0; pi_ < NP; ++pi_)                                                                  \
+      STCAT_PLW_TR8(F.a[pi_][tm], (SB) + ta_lane + ta_seg[tm] + pi_ * PLANE_A, ROWA, KS)                \
   }
 
   STCAT_PL_ACC_INIT
-  constexpr int NMMA = 3 * TM * TN, NRD = 4 * (TM + TN);
-  constexpr int NDMA = 2 * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  constexpr int NMMA = PlProd<NP>::N * TM * TN, NRD = 2 * NP * (TM + TN);
+  constexpr int NDMA = NP * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
   Frag fa, fb;
   STCAT_PLW_STAGE_LOAD(0)
   STCAT_PLW_STAGE_LOAD(1)
@@ -591,9 +654,32 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
 // ---------------------------------------------------------------------------------------------------
 // plane producers / consumers outside the GEMMs
 // ---------------------------------------------------------------------------------------------------
+// split 8 values into np (2 or 3) planes and store them at element offset `at` of each plane
+static __device__ __forceinline__ void stcat_store_planes(const float (&v)[8], __bf16* h, __bf16* l, long at, int np) {
+  if (np == 3) {
+    bf16x8 o[3];
+    stcat_split8n<3>(v, o);
+    *reinterpret_cast<bf16x8*>(h + at) = o[0];
+    *reinterpret_cast<bf16x8*>(l + at) = o[1];
+    *reinterpret_cast<bf16x8*>(stcat_plane(h, l, 2) + at) = o[2];
+  } else {
+    bf16x8 h8, l8;
+    stcat_split8(v, h8, l8);
+    *reinterpret_cast<bf16x8*>(h + at) = h8;
+    *reinterpret_cast<bf16x8*>(l + at) = l8;
+  }
+}
+static __device__ __forceinline__ void stcat_load_planes(const __bf16* h, const __bf16* l, long at, int np, float (&v)[8]) {
+  stcat_join8(h + at, l + at, v);
+  if (np == 3) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(stcat_plane(h, l, 2) + at);
+    STCAT_UNROLL
+    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+  }
+}
 // 3x3 stride-2 pad-1 max-pool, NHWC fp32 in (stem output) -> planes out (input of layer1)
 __global__ void __launch_bounds__(256) maxpool3x3s2_pl_kernel(const float* x, __bf16* yh, __bf16* yl, int n, int H, int W,
-                                                             int C, int OH, int OW) {
+                                                             int C, int OH, int OW, int np) {
   const int c8n = C / 8;
   const long total = (long)n * OH * OW * c8n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -615,10 +701,7 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_pl_kernel(const float* x, __
         m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
       }
     }
-    bf16x8 h8, l8;
-    stcat_split8(m, h8, l8);
-    *reinterpret_cast<bf16x8*>(yh + i * 8) = h8;
-    *reinterpret_cast<bf16x8*>(yl + i * 8) = l8;
+    stcat_store_planes(m, yh, yl, i * 8, np);
   }
 }
 
@@ -633,6 +716,7 @@ struct PlEwParams {
   __bf16* Gh; __bf16* Gl; __bf16* Rh; __bf16* Rl;
   float* of;
   long n8; int C; int mode; int relu;
+  int np;   // planes per set: 2 or 3
 };
 __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n8; i += (long)gridDim.x * blockDim.x) {
@@ -641,7 +725,7 @@ __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
       const float4 a = stcat_ld4(p.xf + i * 8), b = stcat_ld4(p.xf + i * 8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
-      stcat_join8(p.Xh + i * 8, p.Xl + i * 8, v);
+      stcat_load_planes(p.Xh, p.Xl, i * 8, p.np, v);
     }
     if (p.mode == 3) {
       stcat_st4(p.of + i * 8, make_float4(v[0], v[1], v[2], v[3]));
@@ -654,21 +738,14 @@ __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
       STCAT_UNROLL
       for (int e = 0; e < 8; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
     }
-    bf16x8 h8, l8;
-    if (p.Rh) {
-      stcat_split8(v, h8, l8);
-      *reinterpret_cast<bf16x8*>(p.Rh + i * 8) = h8;
-      *reinterpret_cast<bf16x8*>(p.Rl + i * 8) = l8;
-    }
+    if (p.Rh) stcat_store_planes(v, p.Rh, p.Rl, i * 8, p.np);
     if (p.Gh) {
       if (p.scale) {
         const int c = (int)((i * 8) % p.C);
         STCAT_UNROLL
         for (int e = 0; e < 8; ++e) v[e] *= p.scale[c + e];
       }
-      stcat_split8(v, h8, l8);
-      *reinterpret_cast<bf16x8*>(p.Gh + i * 8) = h8;
-      *reinterpret_cast<bf16x8*>(p.Gl + i * 8) = l8;
+      stcat_store_planes(v, p.Gh, p.Gl, i * 8, p.np);
     }
   }
 }
@@ -686,7 +763,15 @@ struct WplEntry {
   int blk0, nbx, nby;
   int pad_;
 };
-__global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry* tab, int n) {
+static __device__ __forceinline__ void stcat_store_planes1(float x, __bf16* h, __bf16* l, long idx, int np) {
+  const __bf16 q0 = (__bf16)x;
+  h[idx] = q0;
+  const float r1 = x - (float)q0;
+  const __bf16 q1 = (__bf16)r1;
+  l[idx] = q1;
+  if (np == 3) stcat_plane(h, l, 2)[idx] = (__bf16)(r1 - (float)q1);
+}
+__global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry* tab, int n, int np) {
   __shared__ float tile[32][33];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -704,9 +789,7 @@ __global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry
     if (co < e.Cout && ci < e.Cin) {
       const long idx = ((long)co * e.taps + tap) * e.Cin + ci;
       x = e.w[idx];
-      const __bf16 h = (__bf16)x;
-      e.wh[idx] = h;
-      e.wl[idx] = (__bf16)(x - (float)h);
+      stcat_store_planes1(x, e.wh, e.wl, idx, np);
     }
     tile[r][tx] = (e.tscale && co < e.Cout) ? x * e.tscale[co] : x;
   }
@@ -717,9 +800,7 @@ __global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry
     if (ci < e.Cin && co < e.Cout) {
       const float x = tile[tx][r];
       const long idx = ((long)tap * e.Cin + ci) * e.Cout + co;
-      const __bf16 h = (__bf16)x;
-      e.th[idx] = h;
-      e.tl[idx] = (__bf16)(x - (float)h);
+      stcat_store_planes1(x, e.th, e.tl, idx, np);
     }
   }
 }

@@ -79,7 +79,8 @@ void pick_tile(int M, int N, int& BM, int& BN) {
 // 0: fp32 MFMA (exact), 2: split-bf16 x3, 3: split-bf16 x6, 4: split-bf16 x3 with the backbone's tensors pre-split into
 // bf16 planes (igemm_pl.h; every other GEMM of the path runs as mode 2)   (stcat_set_mma_mode)
 int g_mma_mode_raw = 0;
-int g_mma_mode = 0;  // what the fp32-tensor kernels see: mode 4 -> 2
+int g_mma_mode = 0;  // what the fp32-tensor kernels see: mode 4 -> 2, mode 5 -> 3
+int g_pl_np = 2;     // planes per tensor of the plane-format entry points: 2 (mode 4) or 3 (mode 5)
 
 #define STCAT_TILE_SWITCH(KERNEL, GRID)                                                        \
   if (BM == 128 && BN == 128) {                                                                \
@@ -314,6 +315,19 @@ int pl_prepare(K kernel, int lds_bytes) {
     if (int rc_ = pl_prepare(KERNEL<BM_, BN_, WM_, WN_>, lds_)) return rc_;                            \
     STCAT_LAUNCH((KERNEL<BM_, BN_, WM_, WN_>), GRID, dim3(512), lds_, st, p);                          \
   }
+// three-plane (mode 5) instantiations: 6 x (BM + BN) x 64 bytes of LDS for the two stages
+#define STCAT_PL3_FWD(BM_, BN_, WM_, WN_, GRID)                                                        \
+  {                                                                                                    \
+    constexpr int lds_ = 6 * (BM_ + BN_) * 64;                                                         \
+    if (int rc_ = pl_prepare(igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3>, lds_)) return rc_;     \
+    STCAT_LAUNCH((igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3>), GRID, dim3(512), lds_, st, p);   \
+  }
+#define STCAT_PL3_WGRAD(BM_, BN_, WM_, WN_, GRID)                                                      \
+  {                                                                                                    \
+    constexpr int lds_ = 6 * (BM_ + BN_) * 64;                                                         \
+    if (int rc_ = pl_prepare(igemm_pl_wgrad_kernel<BM_, BN_, WM_, WN_, 3>, lds_)) return rc_;          \
+    STCAT_LAUNCH((igemm_pl_wgrad_kernel<BM_, BN_, WM_, WN_, 3>), GRID, dim3(512), lds_, st, p);        \
+  }
 
 int g_pl_debug = 0;   // stcat_debug_pl_flags (timing experiments)
 int g_pl_force = -1;  // stcat_debug_force_pl_tile: index into the tile table below, -1 = heuristic
@@ -322,6 +336,28 @@ struct PlTile { int bm, bn; float eff; };
 // (224 x 256: 7 x 32 rows, 8 waves side by side — 50176 = 224 * 224 rows of layer3 fill 224 of 256 CUs in ONE round)
 const PlTile kPlTiles[6] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f},
                             {224, 256, 1.04f}};
+
+// mode 5 (three planes): two stages of 3 x (BM + BN) x 64 bytes must fit 160 KB -> BM + BN <= 384; the six-term
+// contraction issues 24 MFMAs per k-step against 12 fragment reads on the 64 x 64 wave tile of the 256 x 128 shapes
+const float kPl3Eff[6] = {0.f, 1.00f, 1.00f, 1.15f, 1.20f, 0.f};   // indexed like kPlTiles; 0 = not available
+int pick_pl3_tile(int M, int N) {
+  if (g_pl_force >= 0) {
+    int f = g_pl_force;
+    if (kPl3Eff[f] == 0.f) f = 1;                         // 256x256 / 224x256 do not exist with three planes
+    if (N % kPlTiles[f].bn == 0) return f;
+  }
+  int best = -1;
+  float best_cost = 0.f;
+  for (int i = 1; i <= 4; ++i) {
+    const PlTile& tl = kPlTiles[i];
+    if (N % tl.bn != 0) continue;
+    const long tiles = (long)cdiv(M, tl.bm) * (N / tl.bn);
+    const long rounds = (tiles + 255) / 256;
+    const float cost = (float)rounds * tl.bm * tl.bn * kPl3Eff[i];
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  return best;
+}
 
 int pick_pl_tile(int M, int N, int K) {
   if (g_pl_force >= 0 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
@@ -353,10 +389,19 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   // stride-2 data gradient on even dims: parity-class row order (igemm_pl.h, PlParams::par): 4 x tiles(M / 4)
   p.par = (p.g.div == 2 && p.g.mul == 1 && p.g.sgn == -1 && p.g.OH % 2 == 0 && p.g.OW % 2 == 0 && !(g_pl_debug & 4)) ? 1 : 0;
   const int Mrows = p.par ? p.M / 4 : p.M;
-  const int ti = pick_pl_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K);
+  const int ti = g_pl_np == 3 ? pick_pl3_tile(p.par ? p.M : Mrows, p.N) : pick_pl_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K);
   if (ti < 0) return fail("plane GEMM: N = %d is not a multiple of 64", p.N);
   const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
   const dim3 grid((p.par ? 4 : 1) * cdiv(Mrows, BM) * (p.N / BN));
+  if (g_pl_np == 3) {
+    switch (ti) {
+      case 1: STCAT_PL3_FWD(256, 128, 4, 2, grid) break;
+      case 2: STCAT_PL3_FWD(128, 256, 2, 4, grid) break;
+      case 3: STCAT_PL3_FWD(128, 128, 2, 4, grid) break;
+      default: STCAT_PL3_FWD(256, 64, 8, 1, grid) break;
+    }
+    return launch_status();
+  }
   switch (ti) {
     case 0: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 256, 2, 4, grid) break;
     case 1: STCAT_PL_LAUNCH(igemm_pl_fwd_kernel, 256, 128, 4, 2, grid) break;
@@ -431,7 +476,8 @@ int launch_pl_fwd_f32(const IgemmParams& s, hipStream_t st) {
 int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   if (rows % 128 != 0 || p.g.C % 128 != 0) return fail("plane wgrad: need Cout, Cin %% 128 == 0 (%d, %d)", rows, p.g.C);
   const int BM = (rows % 256 == 0 && g_pl_force != 3) ? 256 : 128;
-  const int BN = (p.g.C % 256 == 0 && g_pl_force != 3 && !(BM == 128 && g_pl_force == 3)) ? 256 : 128;
+  // (three planes: BM + BN <= 384, the 256 x 256 tile does not fit)
+  const int BN = (p.g.C % 256 == 0 && g_pl_force != 3 && !(g_pl_np == 3 && BM == 256)) ? 256 : 128;
   const int tiles = (rows / BM) * (cols / BN);
   int nsplit = 256 / tiles;                 // one round of one workgroup per CU
   // The tap tiles of a slice share dY and the (shifted) X pixels through their XCD's 4 MB L2 — if the slice fits.  At
@@ -448,6 +494,12 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   nsplit = cdiv(red, chunk);
   p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk; p.debug = g_pl_debug;
   const dim3 grid(tiles, 1, nsplit);
+  if (g_pl_np == 3) {
+    if (BM == 256) STCAT_PL3_WGRAD(256, 128, 4, 2, grid)
+    else if (BN == 256) STCAT_PL3_WGRAD(128, 256, 2, 4, grid)
+    else STCAT_PL3_WGRAD(128, 128, 2, 4, grid)
+    return launch_status();
+  }
   if (BM == 256 && BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 256, 2, 4, grid)
   else if (BM == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 128, 4, 2, grid)
   else if (BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 128, 256, 2, 4, grid)
@@ -471,10 +523,11 @@ extern "C" {
 
 int stcat_version(void) { return 100; }
 int stcat_set_mma_mode(int mode) {
-  if (mode != 0 && mode != 2 && mode != 3 && mode != 4)
-    return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3), 3 (bf16x6) or 4 (bf16x3 on bf16 planes)");
+  if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5)
+    return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3), 3 (bf16x6), 4 (bf16x3 on two bf16 planes) or 5 (bf16x6 on three)");
   g_mma_mode_raw = mode;
-  g_mma_mode = mode == 4 ? 2 : mode;
+  g_mma_mode = mode == 4 ? 2 : (mode == 5 ? 3 : mode);
+  g_pl_np = mode == 5 ? 3 : 2;
   return 0;
 }
 int stcat_get_mma_mode(void) { return g_mma_mode_raw; }
@@ -1066,13 +1119,14 @@ int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int 
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)n * OH * OW * (C / 8);
   STCAT_LAUNCH(maxpool3x3s2_pl_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
-               (__bf16*)yh, (__bf16*)yl, n, H, W, C, OH, OW);
+               (__bf16*)yh, (__bf16*)yl, n, H, W, C, OH, OW, g_pl_np);
   return launch_status();
 }
 
 static int pl_ew(PlEwParams p, long n, void* stream) {
   if (n <= 0 || n % 8 != 0) return fail("plane element-wise: n = %ld must be a positive multiple of 8", n);
   p.n8 = n / 8;
+  p.np = g_pl_np;
   STCAT_LAUNCH(planes_ew_kernel, dim3(grid_for(p.n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
@@ -1111,7 +1165,7 @@ int stcat_weight_planes_entry_bytes(void) { return (int)sizeof(WplEntry); }
 int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream) {
   if (n_entries <= 0 || total_blocks <= 0) return fail("weight_planes_multi: empty table");
   STCAT_LAUNCH(weight_planes_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WplEntry*)table,
-               n_entries);
+               n_entries, g_pl_np);
   return launch_status();
 }
 

@@ -721,7 +721,8 @@ class MhaSelfFn(Function):
         # bf16-pipe kernels (csrc/attention_bs.h): online softmax, any S, only the row log-sum-exp is kept for backward.
         # The fp32-MFMA kernels remain for the exact-fp32 mode and for the one caller that consumes the head-mean
         # weights (the time decoder's self-attention, T queries).
-        ctx.bs = (not need_weights) and L.get_mma_mode() != "f32"
+        # (mode bf16x6p is fp32-class end to end: its attention runs on the fp32 matrix pipe as well)
+        ctx.bs = (not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p")
         if ctx.bs:
             keep = any(ctx.needs_input_grad[:3])
             lse = _empty(v, B, H, S) if keep else None
@@ -1064,17 +1065,19 @@ WEIGHT_EPOCH = 0  # bumped by the fused optimizer (it updates parameters through
 
 
 class Planes:
-    """A tensor held as two bf16 planes (hi = bf16(x), lo = bf16(x - hi)) in ONE allocation [2, *shape]."""
+    """A tensor held as bf16 planes in ONE allocation [NP, *shape]: NP = 2 in mode bf16x3p (hi = bf16(x),
+    lo = bf16(x - hi): 16 significand bits), NP = 3 in mode bf16x6p (hi + mid + lo == x exactly).  The C ABI takes the
+    first two plane pointers; the third plane lies at the same spacing behind the second."""
     __slots__ = ("t", "mask")
 
     def __init__(self, t: torch.Tensor, mask: Optional[torch.Tensor] = None):
-        assert t.dtype == _bf16 and t.shape[0] == 2 and t.is_contiguous()
+        assert t.dtype == _bf16 and t.shape[0] == L.plane_count() and t.is_contiguous(), (t.dtype, t.shape, L.get_mma_mode())
         self.t = t
         self.mask = mask  # optional bit mask (x > 0), uint8 [rows, C / 8], written by the producing conv epilogue
 
     @staticmethod
     def empty(like: torch.Tensor, *shape) -> "Planes":
-        return Planes(torch.empty((2, *shape), device=like.device, dtype=_bf16))
+        return Planes(torch.empty((L.plane_count(), *shape), device=like.device, dtype=_bf16))
 
     @property
     def shape(self):

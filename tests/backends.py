@@ -41,6 +41,7 @@ def use_emu():
     import ctypes
     L._lib = L._bind(ctypes.CDLL(EMU_SO))
     L._backend = "emu"
+    L._mode_cache = None
     return torch.device("cpu")
 
 
@@ -49,6 +50,7 @@ def use_hip():
         pytest.skip("no GPU")
     L._lib = None
     L._backend = "hip"
+    L._mode_cache = None
     L.load()
     return torch.device("cuda:0")
 

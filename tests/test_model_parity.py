@@ -297,7 +297,7 @@ def test_gpu_c1_forward_backward(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6", "bf16x3p"])
+@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6", "bf16x3p", "bf16x6p"])
 def test_gpu_c1_split_bf16_modes(mma):
     """The split-bf16 GEMM modes must meet the same bars as the fp32-MFMA mode."""
     dev = use_hip()
@@ -315,6 +315,14 @@ def test_emu_tiny_clip_bf16x3_planes():
     # several 1e-2; the residual stream also carries 16 instead of 24 significand bits here)
     _compare(_run_hip(dev, 2, 64, 3, mma="bf16x3p"), _run_oracle(2, 64, 3), g64=g64,
              grad_caps={k: min(16 * v, 0.1) for k, v in GRAD_CAPS_16BIT.items()})
+
+
+def test_emu_tiny_clip_bf16x6_planes():
+    """mma mode bf16x6p (the bench default): three-plane backbone (fp32 values exactly, six-term products), bf16x6 Linear
+    layers, fp32-pipe attention — held to the calibrated fp32-class gradient bound, like f32 / bf16x6."""
+    dev = use_emu()
+    g64 = _run_oracle(2, 64, 3, dtype=torch.float64)[4]
+    _compare(_run_hip(dev, 2, 64, 3, mma="bf16x6p"), _run_oracle(2, 64, 3), g64=g64)
 
 
 def test_emu_tiny_clip_bf16x3():

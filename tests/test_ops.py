@@ -154,7 +154,21 @@ def _conv(dev, big):
 # ---------------------------------------------------------------------------------------
 # plane-format conv family (mma mode "bf16x3p", csrc/igemm_pl.h): operands pre-split into bf16 hi/lo planes
 # ---------------------------------------------------------------------------------------
-def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, wgrad=True):
+def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, wgrad=True, mode="bf16x3p"):
+    """mode bf16x3p: two planes (16 significand bits, split error 2^-17); bf16x6p: three planes = the fp32 value exactly,
+    six-term products (fp32-class: held to a 10x tighter bound than the 16-bit mode)"""
+    old_mode = L.get_mma_mode()
+    L.set_mma_mode(mode)
+    try:
+        _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgrad, mode)
+    finally:
+        L.set_mma_mode(old_mode)
+
+
+def _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgrad, mode):
+    exact = mode == "bf16x6p"
+    TOL = 2e-5 if exact else 2e-4
+    RT = 0.0 if exact else 2e-5           # split / join round trip
     x = rnd(n, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
     scale, bias = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
@@ -172,13 +186,13 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
     wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
     sd, bd = scale.to(dev), bias.to(dev)
     xp = ops.pl_split(xd)
-    close(ops.pl_join(xp), xd, 2e-5, "split/join round trip")  # hi + lo carries 16 significand bits
+    close(ops.pl_join(xp), xd, RT, "split/join round trip")  # hi + lo carries 16 significand bits
     rp = ops.pl_split(r.permute(0, 2, 3, 1).contiguous().to(dev)) if res else None
     cache = ops.WeightPlanes()
     wp, wt = cache.refresh([wd], transposed=True)
     wp, wt = wp[wd.data_ptr()], wt[wd.data_ptr()]
-    close(ops.pl_join(wp), wd, 2e-5, "weight planes")
-    close(ops.pl_join(wt), wd.view(Cout, k * k, Cin).permute(1, 2, 0), 2e-5, "transposed weight planes")
+    close(ops.pl_join(wp), wd, RT, "weight planes")
+    close(ops.pl_join(wt), wd.view(Cout, k * k, Cin).permute(1, 2, 0), RT, "transposed weight planes")
     L.call("stcat_debug_force_pl_tile", tile)
     try:
         yp, yf = ops.pl_conv_fwd_raw(xp, wp, sd, bd, rp, stride, pad, relu, planes_out=True, f32_out=True, want_mask=True)
@@ -207,9 +221,9 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
         dw_sref = ops.pl_conv_wgrad_raw(Gs, xp, wd.shape, stride, pad).clone() if wgrad else None
     finally:
         L.call("stcat_debug_force_pl_tile", -1)
-    tag = f"plane conv {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
+    tag = f"plane conv [{mode}] {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
     close(yf.permute(0, 3, 1, 2), ref, TOL, tag + " fwd (fp32 out)")
-    close(ops.pl_join(yp), yf, 2e-5, tag + " fwd (planes out)")
+    close(ops.pl_join(yp), yf, RT, tag + " fwd (planes out)")
     close(ops.pl_join(dx).permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
     ref3 = xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0) * msc.cpu()
     close(ops.pl_join(dx3), ref3, TOL, tag + " dgrad+fused relu/bn backward")
@@ -224,7 +238,7 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
         close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
     if res:
         mask = (ref > 0).float() if relu else torch.ones_like(ref)
-        close(ops.pl_join(dres).permute(0, 3, 1, 2), gy * mask, 2e-5, tag + " dres")
+        close(ops.pl_join(dres).permute(0, 3, 1, 2), gy * mask, RT, tag + " dres")
 
 
 @both
@@ -240,7 +254,22 @@ def _pl_conv(dev, big):
     _pl_conv_case(dev, 2, 6, 10, 64, 64, 3, 2, 1, relu=True, res=False, tile=4, wgrad=False)
     _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2)
     _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0)
+    # three-plane mode (bf16x6p): its four tile shapes (1: 256x128, 2: 128x256, 3: 128x128, 4: 256x64), the parity-class
+    # data gradient, residual planes, both wgrad tile families
+    _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=4, wgrad=False, mode="bf16x6p")
+    _pl_conv_case(dev, 1, 9, 7, 128, 128, 1, 2, 0, relu=False, res=False, tile=1, mode="bf16x6p")
+    _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=3, mode="bf16x6p")
+    _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2, mode="bf16x6p")
+    _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0, mode="bf16x6p")
     if big:
+        for m3 in ("bf16x6p",):
+            _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, mode=m3)
+            _pl_conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False, mode=m3)
+            _pl_conv_case(dev, 4, 28, 28, 512, 1024, 1, 2, 0, relu=False, res=False, mode=m3)
+            _pl_conv_case(dev, 4, 14, 14, 1024, 256, 1, 1, 0, relu=True, res=True, mode=m3)
+            _pl_conv_case(dev, 8, 56, 56, 256, 128, 1, 1, 0, relu=True, res=False, mode=m3)
+            _pl_conv_case(dev, 8, 56, 56, 64, 64, 3, 1, 1, relu=True, res=False, wgrad=False, mode=m3)
+            _pl_conv_case(dev, 16, 14, 14, 512, 512, 3, 1, 1, relu=True, res=False, mode=m3)
         _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False)
         _pl_conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False)
         _pl_conv_case(dev, 4, 28, 28, 512, 1024, 1, 2, 0, relu=False, res=False)
@@ -255,8 +284,15 @@ def _pl_maxpool(dev, big):
     n, H, C = (2, 10, 64) if not big else (4, 112, 64)
     x = rnd(n, C, H, H, seed=1)
     ref = F.max_pool2d(x, 3, 2, 1)
-    y = ops.pl_maxpool_raw(x.permute(0, 2, 3, 1).contiguous().to(dev))
-    close(ops.pl_join(y).permute(0, 3, 1, 2), ref, 2e-5, "plane maxpool")
+    old_mode = L.get_mma_mode()
+    try:
+        for mode, tol in (("bf16x3p", 2e-5), ("bf16x6p", 0.0)):
+            L.set_mma_mode(mode)
+            y = ops.pl_maxpool_raw(x.permute(0, 2, 3, 1).contiguous().to(dev))
+            assert y.t.shape[0] == (3 if mode == "bf16x6p" else 2)
+            close(ops.pl_join(y).permute(0, 3, 1, 2), ref, tol, f"plane maxpool [{mode}]")
+    finally:
+        L.set_mma_mode(old_mode)
 
 
 @both

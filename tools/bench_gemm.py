@@ -69,7 +69,7 @@ def main():
     for name, n, H, W, Cin, Cout, k, stride, pad in SHAPES:
         if args.only and args.only not in name:
             continue
-        if args.mma == "bf16x3p":
+        if args.mma in ("bf16x3p", "bf16x6p"):
             if n == 1:
                 continue  # the Linear shapes stay on the fp32-tensor kernels
             if args.pl_tile >= 0:
