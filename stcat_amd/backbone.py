@@ -188,6 +188,7 @@ class _BackboneFn(Function):
             g = grads.get(id(w))
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)  # OHWI buffer seen as [O,I,KH,KW]
         ctx.tape = None
+        ops.dropout_backward_done()
         return (None, None, *out)
 
 
@@ -303,6 +304,7 @@ class _BackboneFnPl(Function):
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)
         ctx.tape = None
         ctx.wt = None
+        ops.dropout_backward_done()
         return (None, None, *out)
 
 
@@ -327,6 +329,7 @@ class Backbone(nn.Module):
             # first module of the hot path to run in a step: open the step's dropout counter range (drop-in mode has
             # no other place to do it — the reference's train loop is unmodified)
             ops.dropout_auto_begin_step(frames.device)
+            ops.dropout_forward_started()
         weights = self._plist  # same order as body.parameters(): the backward returns one gradient per entry
         if weights is None or len(weights) == 0:
             weights = self._plist = [p for p in self.body.parameters()]

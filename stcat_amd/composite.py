@@ -661,6 +661,7 @@ class EncoderFn(Function):
         flat = ()
         for g in grads:
             flat += tuple(g)
+        ops.dropout_backward_done()   # (a frozen backbone has no backward node: this is then the path's last one)
         return (d_vis, d_txt, None, None, None, None, None, None, d_fc, ops.colsum(d_lp).view(1, d),
                 ops.ew(L.EW_COPY, d_video)) + flat
 

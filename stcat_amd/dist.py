@@ -140,15 +140,31 @@ class GradBucketReducer:
         for p, g in zip(params, grads):
             if p not in self._view_of:
                 return False          # (a parameter outside the buckets: let autograd handle the whole group)
+        # Stream contract: the caller's CURRENT stream is the one that produced `grads` (the backbone calls this inside
+        # `with WgradStream`); the copies and the collective launched below are ordered behind it.
+        again_s, again_d = [], []
         for p, g in zip(params, grads):
+            b = self.buckets[self._owner[p]]
+            if p in self._early:
+                # second delivery in one step (two backward passes before finish(): gradient accumulation): add, as
+                # AccumulateGrad would; a bucket that was already reduced cannot take it any more
+                if b["pending"] < 0:
+                    raise RuntimeError("GradBucketReducer.early: a bucket was already all-reduced when a second gradient "
+                                       "for one of its parameters arrived; call finish() between backward passes or "
+                                       "run gradient accumulation with STCAT_REDUCER_NO_OVERLAP=1")
+                again_s.append(g)
+                again_d.append(self._view_of[p])
+                continue
             srcs.append(g)
             dsts.append(self._view_of[p])
             self._early.add(p)
-            b = self.buckets[self._owner[p]]
             b["pending"] -= 1
             if b["pending"] == 0:
                 touched.append(b)
-        torch._foreach_copy_(dsts, srcs)
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        if again_s:
+            torch._foreach_add_(again_d, again_s)
         for b in touched:
             if not b["late"] and not self.no_overlap:
                 self._launch(b)

@@ -255,6 +255,11 @@ class StgLossFn(Function):
         _chk(boxes, sted, w, act, wmat)
         nl = boxes.shape[0]
         assert sted.shape == (nl, plan.b, plan.T, 2) and w.shape == (nl, plan.b, plan.T, plan.T)
+        # the kernels index boxes / targets / logits with the plan's rows: a mismatch must raise here, as the reference's
+        # F.l1_loss does, not read out of bounds
+        assert boxes.dim() == 3 and boxes.shape[2] == 4 and boxes.shape[1] == plan.b * plan.T, (boxes.shape, plan.b, plan.T)
+        assert tuple(plan.tgt_boxes.shape) == (plan.rows.numel(), 4), (plan.tgt_boxes.shape, plan.rows.numel())
+        assert act is None or tuple(act.shape) == (nl, plan.b, plan.T), act.shape
         vec = _empty(boxes, 5, nl)
         total = _zeros(boxes, 1) if wmat is not None else None
         L.call("stcat_stg_loss_fwd", *StgLossFn._args(boxes, sted, w, act, plan), L._ptr(wmat), vec.data_ptr(), L._ptr(total),
@@ -560,11 +565,14 @@ class _DropoutStream:
     per-process generators differ."""
 
     STEP_SPAN = 1 << 36  # counters reserved per step (a C5 step uses ~2^33)
+    SLOTS = 8            # device base words: a forward whose backward is still outstanding keeps its own (ADVICE r02)
 
     def __init__(self):
         self.seed = None   # resolved lazily: manual_seed(), else from torch.initial_seed() and the DP rank
         self.offset = 0
-        self._base = {}
+        self._base = {}    # device -> int64 [1 + SLOTS]: word 0 = master counter, words 1.. = the slots the kernels read
+        self._slot = {}    # device -> index of the current slot
+        self.pending = False   # a train-mode forward ran and its backward has not finished yet
 
     def _default_seed(self) -> int:
         """Drop-in mode never calls manual_seed: the reference seeds torch with 42 + rank (scripts/train_net.py:296),
@@ -578,11 +586,18 @@ class _DropoutStream:
             pass
         return _mix_seed(torch.initial_seed() & _MASK64, rank)
 
-    def base(self, device) -> torch.Tensor:
+    def _words(self, device) -> torch.Tensor:
         b = self._base.get(device)
         if b is None:
-            b = self._base[device] = torch.zeros(1, dtype=torch.int64, device=device)
+            b = self._base[device] = torch.zeros(1 + self.SLOTS, dtype=torch.int64, device=device)
+            self._slot[device] = 0
         return b
+
+    def base(self, device) -> torch.Tensor:
+        """the device word the kernels of the CURRENT forward (and of its backward) read their counter base from"""
+        w = self._words(device)
+        k = self._slot[device]
+        return w[1 + k:2 + k]
 
     def take(self, numel: int, device):
         if self.seed is None:
@@ -594,8 +609,18 @@ class _DropoutStream:
         return self.seed, off, self.base(device).data_ptr()
 
     def begin_step(self, device):
+        """Open a new counter range.  The master word advances in place (stream-ordered, capturable: a replayed
+        hipGraph draws fresh masks), then lands in the slot the next forward's kernels read.  The slot only moves on
+        when the previous forward's backward is still outstanding (gradient accumulation over several clips, two
+        losses): that backward regenerates its masks from ITS slot, which this step must not touch.  A plain
+        forward / backward loop stays on one slot, so launch arguments are identical from step to step."""
         self.offset = 0
-        self.base(device).add_(self.STEP_SPAN)  # stream-ordered (and capturable): no host sync
+        w = self._words(device)
+        capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.pending and not capturing:
+            self._slot[device] = (self._slot[device] + 1) % self.SLOTS
+        w[0:1].add_(self.STEP_SPAN)
+        self.base(device).copy_(w[0:1])
 
     def auto_begin_step(self, device):
         """Called at the top of every train-mode forward (the visual encoder is the first module of the path to
@@ -619,8 +644,10 @@ def manual_seed(seed: int, rank: int = 0) -> None:
     """Seed the dropout stream of this process (counters restart at 0)."""
     _dropout_stream.seed = _mix_seed(seed, rank)
     _dropout_stream.offset = 0
-    for b in _dropout_stream._base.values():
+    _dropout_stream.pending = False
+    for d, b in _dropout_stream._base.items():
         b.zero_()
+        _dropout_stream._slot[d] = 0
 
 
 def dropout_begin_step(device) -> None:
@@ -631,6 +658,16 @@ def dropout_begin_step(device) -> None:
 def dropout_auto_begin_step(device) -> None:
     """Start a new step's counter range if the previous one was used (see _DropoutStream.auto_begin_step)."""
     _dropout_stream.auto_begin_step(torch.device(device))
+
+
+def dropout_forward_started() -> None:
+    """a train-mode forward with gradients is under way: its masks belong to the current slot until its backward ran"""
+    _dropout_stream.pending = True
+
+
+def dropout_backward_done() -> None:
+    """called by the last backward node of the path (encoder, then backbone): the slot may be reused by the next step"""
+    _dropout_stream.pending = False
 
 
 def dropout_stream_state():
@@ -1228,7 +1265,10 @@ class WeightPlanes:
             self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(weights[0].device)
             self.total, self.key, self.n, self.state = blk, key, len(weights), None
         state = (WEIGHT_EPOCH, tuple(w._version for w in weights))
-        if state != self.state:
+        # (while a hipGraph is being captured the launch must be part of it: the replayed step follows an optimizer
+        # step that moved the fp32 weights — ADVICE r02)
+        capturing = weights[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        if state != self.state or capturing:
             L.call("stcat_weight_planes_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
             self.state = state
         return self.fwd, self.tr

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     _lib.load()
-    _lib.set_mma_mode("bf16x3p")
+    _lib.set_mma_mode("bf16x6p")
     T, res, L = synth.CONFIGS["C1"]
     model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
     synth.fill_module_(model)

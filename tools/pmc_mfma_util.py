@@ -8,7 +8,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SIMDS = 256 * 4
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -41,6 +44,7 @@ for k, v in agg.items():
         continue
     out[k] = {"launches": n, "mfma_util_pct": round(100.0 * busy / (act * SIMDS), 2),
               "mfma_busy_cycles_per_launch": round(busy / n), "gpu_active_cycles_per_launch": round(act / n)}
-print(json.dumps({"note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), rocprofv3 --pmc, own pass; "
+from bench import source_sha  # noqa: E402
+print(json.dumps({"source_sha": source_sha(), "note": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), rocprofv3 --pmc, own pass; "
                           "GRBM_GUI_ACTIVE arrives summed over the 8 XCDs and is divided by 8",
                   "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["mfma_busy_cycles_per_launch"] * kv[1]["launches"]))}))

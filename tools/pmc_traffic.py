@@ -6,7 +6,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def collect(d, counter):
@@ -30,4 +33,5 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 1))[0]
     name = k.split("(")[0][:60]
     out[name] = {"launches": fn, "read_MB_per_launch": round(2 * fs * 1024 / max(fn, 1) / 1e6, 3),
                  "write_MB_per_launch": round(ws * 1024 / max(wn, 1) / 1e6, 3)}
-print(json.dumps({"note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; per launch", "kernels": out}))
+from bench import source_sha  # noqa: E402
+print(json.dumps({"source_sha": source_sha(), "note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; per launch", "kernels": out}))
