@@ -30,7 +30,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stcat_amd import _lib, ops, synth  # noqa: E402
+from stcat_amd import _lib, ops, plans, synth  # noqa: E402
 from stcat_amd.dist import GradBucketReducer  # noqa: E402
 from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
 from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
@@ -266,6 +266,9 @@ def main():
                     help="replay the step as one captured hipGraph (stcat_amd/graph.py) instead of enqueuing it launch "
                          "by launch from Python; measured SLOWER on ROCm 7.2 (hipGraphLaunch walks ~3500 nodes on the "
                          "host: 99.5 vs 88.5 ms/step), so it is opt-in")
+    ap.add_argument("--no-plans", action="store_true",
+                    help="issue every launch from Python (round-2 behaviour) instead of replaying the composite nodes' "
+                         "recorded launch plans with one C call each (stcat_amd/plans.py, csrc/launch_plan.h)")
     ap.add_argument("--no-optim", action="store_true", help="skip the (untimed-in-metric) optimizer-tail timing")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
@@ -380,6 +383,13 @@ def main():
             reducer.finish()
             return total
 
+    use_plans = not args.no_plans and not args.graph
+    plans.enable(use_plans)
+    if use_plans:
+        # a node runs eagerly the first time it sees a signature and is recorded the second time: both happen here, so
+        # the W warm-up steps and the K timed steps are all replays, whatever W is
+        for _ in range(2):
+            step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -405,12 +415,15 @@ def main():
         step = eager_step
     roof, kernels, gemm_shapes = None, None, None
     if not args.no_profile:
-        # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events
+        # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events.
+        # It brackets every launch with HIP events from Python, so it runs launch by launch (same kernels, same order)
+        plans.enable(False)
         if rank == 0:
             with LaunchProfiler() as prof:
                 step()
         else:
             step()
+        plans.enable(use_plans)
     if rank == 0 and not args.no_profile:
         agg = prof.summary()
         kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -470,8 +483,11 @@ def main():
             if mode == args.mma:
                 continue
             _lib.set_mma_mode(mode)
-            for _ in range(3):     # (a mode switch re-creates the weight-plane / transposed-weight caches: warm up)
-                step()
+            if use_plans:          # the plans of the previous mode hold tens of GB of static activations: drop them
+                plans.clear()
+                torch.cuda.empty_cache()
+            for _ in range(3):     # (a mode switch re-creates the weight-plane / transposed-weight caches: warm up;
+                step()             #  with launch plans: eager, record, first replay)
             fence()
             t1 = time.perf_counter()
             for _ in range(10):
@@ -481,6 +497,9 @@ def main():
             other_modes[mode] = {"mma": notes[mode], "value": round(1.0 / dt_m, 4), "ms_per_step": round(1e3 * dt_m, 2),
                                  "steps": 10, "warmup": 3}
         _lib.set_mma_mode(args.mma)
+        if use_plans:
+            plans.clear()
+            torch.cuda.empty_cache()
         exact = other_modes.get("f32")
     throughput_mode = None
     if other_modes and "bf16x3p" in other_modes:
@@ -602,7 +621,10 @@ def main():
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",
-                       "launch": "one hipGraph per step" if args.graph else "eager (launch by launch)",
+                       "launch": ("one hipGraph per step" if args.graph else
+                                  "launch plans: one C call replays each composite node's recorded launch sequence "
+                                  "(backbone fwd/bwd, encoder, box/time decoder, heads)" if use_plans else
+                                  "eager (launch by launch from Python)"),
                        "allreduce_bytes": reducer.message_bytes},
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "throughput_mode": throughput_mode,
             "other_modes": other_modes,

@@ -312,6 +312,31 @@ int stcat_ema_update(const void* table, const int* chunk_tensor, const long* chu
 /* sted [b,T,2], durations [b] (device int32) -> out [b,2] device int32 (start_idx, end_idx), T <= 1024 */
 int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out, int b, int T, void* stream);
 
+/* ---- launch plans: the host side of a composite node of the path — models/vision_model/backbone.py:93-121 (the
+ *      backbone forward / backward), grounding_model/modal_encoder.py:104-204 (encoder), grounding_model/
+ *      query_decoder.py:150-247 and :478-550 (box / time decoder), models/pipeline.py:88-103 (heads), called in the
+ *      order of models/pipeline.py:52-121 — as ONE call.  The launch sequence (every entry point above that takes a
+ *      stream) is recorded once per input shape and replayed by stcat_plan_run(): one hipLaunchKernel per op instead
+ *      of one Python -> FFI round trip per op.  Argument words: one 64-bit word per argument (pointers and integers
+ *      as is, floats as their IEEE bits in the low half); the stream argument is filled in from `streams[slot]` at
+ *      replay.  Relocations patch the pointers that lie inside the caller's per-step tensors ("externals"). -------- */
+int stcat_plan_fn_index(const char* entry_point_name);                  /* -1: not a launch entry point */
+int stcat_plan_fn_nargs(int fn);
+void* stcat_plan_create(void);
+int stcat_plan_destroy(void* plan);
+/* returns the index of the call's first argument word (>= 0) or < 0 */
+int stcat_plan_add_call(void* plan, int fn, const unsigned long long* words, int nargs, int stream_slot, int stream_arg);
+/* everything issued later on `waiter_slot` waits for what is queued on `signal_slot` at this point of the replay */
+int stcat_plan_add_wait(void* plan, int waiter_slot, int signal_slot);
+/* zero `bytes` at ptr (the plan's accumulation buffers); at_front: before every other op; returns the pointer's word */
+int stcat_plan_add_memset(void* plan, void* ptr, unsigned long long bytes, int stream_slot, int at_front);
+/* the replay returns to the host here (tag identifies the host-side action), to be resumed at *next */
+int stcat_plan_add_yield(void* plan, int tag);
+int stcat_plan_add_reloc(void* plan, int word, int external, unsigned long long byte_offset);
+int stcat_plan_size(void* plan, int* n_ops, int* n_words, int* n_relocs);
+int stcat_plan_run(void* plan, const unsigned long long* externals, int n_externals, void* const* streams, int n_streams,
+                   int start, int* next, int* tag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,9 +79,22 @@ SIGNATURES: Dict[str, str] = {
     "stcat_debug_streamk": "i",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
+    # launch plans (csrc/launch_plan.h): P = host pointer, u = unsigned 64-bit, S = C string
+    "stcat_plan_fn_index": "S",
+    "stcat_plan_fn_nargs": "i",
+    "stcat_plan_create": "",
+    "stcat_plan_destroy": "P",
+    "stcat_plan_add_call": "PiPiii",
+    "stcat_plan_add_wait": "Pii",
+    "stcat_plan_add_memset": "Ppuii",
+    "stcat_plan_add_yield": "Pi",
+    "stcat_plan_add_reloc": "Piiu",
+    "stcat_plan_size": "PPPP",
+    "stcat_plan_run": "PPiPiiPP",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p,
-       "P": ctypes.c_void_p}  # P = HOST pointer (small by-value arrays)
+       "P": ctypes.c_void_p,  # P = HOST pointer (small by-value arrays, plan handles)
+       "u": ctypes.c_ulonglong, "S": ctypes.c_char_p}
 
 EW_ADD, EW_MUL, EW_SIGMOID, EW_TANH, EW_RELU, EW_INVSIG = 0, 1, 2, 3, 4, 5
 EW_SIGMOID_BWD, EW_TANH_BWD, EW_INVSIG_BWD, EW_ADD3, EW_AXPBY, EW_COPY = 6, 7, 8, 9, 10, 11
@@ -99,6 +112,7 @@ def _bind(lib: ctypes.CDLL) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.argtypes = [_CT[c] for c in sig]
         fn.restype = ctypes.c_int
+    lib.stcat_plan_create.restype = ctypes.c_void_p
     lib.stcat_version.restype = ctypes.c_int
     lib.stcat_last_error.restype = ctypes.c_char_p
     return lib
@@ -173,12 +187,17 @@ def check_tensor(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     return t
 
 
+RECORDER = None  # stcat_amd.plans.Recorder while a launch plan is being recorded (the calls still execute)
+
+
 def call(name: str, *args) -> None:
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.stcat_last_error()
         raise StcatHipError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
+    if RECORDER is not None:
+        RECORDER.add_call(name, args)
 
 
 def pin_host_threads_to_gpu(device_index: int = 0) -> Optional[str]:

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import ops
+from . import ops, plans
 from .misc import NestedTensor
 
 BLOCKS = (3, 4, 23, 3)
@@ -187,7 +187,8 @@ class _BackboneFn(Function):
         for w in ctx.plist:  # same order as the *weights passed to forward
             g = grads.get(id(w))
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)  # OHWI buffer seen as [O,I,KH,KW]
-        ctx.tape = None
+        if not getattr(ctx, "static", False):
+            ctx.tape = None
         ops.dropout_backward_done()
         return (None, None, *out)
 
@@ -286,8 +287,9 @@ class _BackboneFnPl(Function):
                 ws = [blk.conv3.weight, blk.conv2.weight, blk.conv1.weight]
                 if wd is not None:
                     ws.append(blk.downsample[0].weight)
-                with wg:
-                    if sink.early(ws, [grads[id(w_)].permute(0, 3, 1, 2) for w_ in ws]):
+                gs = [grads[id(w_)].permute(0, 3, 1, 2) for w_ in ws]
+                with wg:    # (a launch plan replays the hand-over at this point of the sequence, on this stream)
+                    if ops.host_call(lambda ws=ws, gs=gs: sink.early(ws, gs)):
                         delivered.update(id(w_) for w_ in ws)
             if not need_dx:
                 break
@@ -302,8 +304,9 @@ class _BackboneFnPl(Function):
         for w in ctx.plist:
             g = grads.get(id(w)) if id(w) not in delivered else None
             out.append(g.permute(0, 3, 1, 2) if g is not None else None)
-        ctx.tape = None
-        ctx.wt = None
+        if not getattr(ctx, "static", False):     # (a launch plan keeps the node's state: its tensors are static)
+            ctx.tape = None
+            ctx.wt = None
         ops.dropout_backward_done()
         return (None, None, *out)
 
@@ -334,8 +337,8 @@ class Backbone(nn.Module):
         if weights is None or len(weights) == 0:
             weights = self._plist = [p for p in self.body.parameters()]
         if ops.L.plane_count():
-            return _BackboneFnPl.apply(frames, self.body, *weights)
-        return _BackboneFn.apply(frames, self.body, *weights)
+            return plans.apply(_BackboneFnPl, frames, self.body, *weights)
+        return plans.apply(_BackboneFn, frames, self.body, *weights)
 
     def forward(self, tensor_list: NestedTensor):
         feat = self.features_nhwc(tensor_list.tensors)

@@ -18,7 +18,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
-from . import ops
+from . import ops, plans
 
 ENABLED = not os.environ.get("STCAT_NO_COMPOSITE")
 
@@ -79,8 +79,7 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
             if add is not None:
                 add = add.reshape(M, K)
                 add = add if add.is_contiguous() else add.contiguous()
-            arena = ops._ARENA.get(str(g.device)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32") else None
-            dx = arena.take((M, K)) if arena is not None else None
+            dx = ops._zero_take(g, (M, K)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32") else None
             if dx is not None:       # skinny: zeroed output, reduction split over grid.z (see ops.linear_fwd_raw)
                 L.call("stcat_linear_dgrad_acc", g.data_ptr(), w.data_ptr(), L._ptr(add), dx.data_ptr(), M, N, K, N, K, st)
             else:
@@ -246,7 +245,8 @@ class TimeDecoderFn(Function):
         T, D = query_pos.shape
         hd = D // nhead
         memory = memory if memory.is_contiguous() else memory.contiguous()
-        query_pos = query_pos if query_pos.is_contiguous() else query_pos.contiguous()
+        if not query_pos.is_contiguous():     # the template's content row, expanded over the frames (:463): our own copy
+            query_pos = ops.ew2d(L.EW_COPY, query_pos) if query_pos.stride(1) == 1 else query_pos.contiguous()
         mem_pos = ops.ew(L.EW_ADD, memory, pos)                                               # :636
         qpos_time = ops.ew(L.EW_ADD, query_pos, time_pos)                                     # :602
         hs = ops._empty(memory, nl, T, D)
@@ -341,7 +341,7 @@ def time_decoder(dec, memory, pos, kpm, query_pos, time_pos):
         sa, ca = l.self_attn, l.cross_attn_image
         prm += ((sa.in_proj_weight, sa.in_proj_bias) + wb(sa.out_proj) + wb(l.norm1) + (ca.in_proj_weight, ca.in_proj_bias)
                 + wb(ca.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2) + wb(l.norm4))
-    return TimeDecoderFn.apply(memory, pos, kpm, query_pos, time_pos, p, dec.layers[0].nhead, len(dec.layers),
+    return plans.apply(TimeDecoderFn, memory, pos, kpm, query_pos, time_pos, p, dec.layers[0].nhead, len(dec.layers),
                                dec.norm.weight, dec.norm.bias, *prm)
 
 
@@ -563,7 +563,7 @@ def box_decoder(dec, memory, pos, kpm, anchor, time_embed):
                 + wb(l.ca_qcontent_proj) + (wb(l.ca_qpos_proj) if l.ca_qpos_proj is not None else (None, None))
                 + wb(l.ca_qpos_sine_proj) + wb(l.cross_attn.out_proj) + wb(l.norm3) + wb(l.linear1) + wb(l.linear2)
                 + wb(l.norm4) + wb(l.ca_kcontent_proj) + wb(l.ca_kpos_proj) + wb(l.ca_v_proj))
-    return BoxDecoderFn.apply(memory, pos, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)
+    return plans.apply(BoxDecoderFn, memory, pos, kpm, anchor, time_embed, p, dec.layers[0].nhead, dec.num_layers, *prm)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -675,7 +675,7 @@ def encoder(enc, vis_tokens, txt, vis_pos, kpm_full, tpos):
             sa = l.self_attn
             prm += (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, l.norm1.weight, l.norm1.bias,
                     l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias)
-    return EncoderFn.apply(vis_tokens, txt, vis_pos, kpm_full, tpos, p, enc.spatial_layers[0].nhead, enc.num_layers,
+    return plans.apply(EncoderFn, vis_tokens, txt, vis_pos, kpm_full, tpos, p, enc.spatial_layers[0].nhead, enc.num_layers,
                            enc.frame_cls.weight, enc.local_pos_embed.weight, enc.video_cls.weight, *prm)
 
 
@@ -734,4 +734,4 @@ def time_heads(temp_embed, action_embed, time_hs):
     p = temp_embed.dropout_p if temp_embed.training else 0.0
     wb = lambda m: (m.weight, m.bias)       # noqa: E731
     a = (wb(action_embed.layers[0]) + wb(action_embed.layers[1])) if action_embed is not None else (None,) * 4
-    return TimeHeadsFn.apply(time_hs, p, *(wb(temp_embed.layers[0]) + wb(temp_embed.layers[1])), *a)
+    return plans.apply(TimeHeadsFn, time_hs, p, *(wb(temp_embed.layers[0]) + wb(temp_embed.layers[1])), *a)

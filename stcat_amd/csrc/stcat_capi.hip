@@ -1246,3 +1246,213 @@ int stcat_rowscale(float* y, const float* w, long rows, int C, int period, void*
 }
 
 }  // extern "C"
+
+// ---- launch plans (launch_plan.h): record once, replay with one host call -----------------------------------------
+#include "launch_plan.h"
+
+namespace {
+#define STCAT_PLAN_FN(name) \
+  { #name, &stcat_plan::Thunk<decltype(&name), &name>::call, stcat_plan::Thunk<decltype(&name), &name>::nargs }
+const stcat_plan::FnEntry g_plan_fns[] = {
+    STCAT_PLAN_FN(stcat_frozen_bn_fold),
+    STCAT_PLAN_FN(stcat_stem_fwd),
+    STCAT_PLAN_FN(stcat_stem_u8_fwd),
+    STCAT_PLAN_FN(stcat_maxpool3x3s2),
+    STCAT_PLAN_FN(stcat_conv_fwd),
+    STCAT_PLAN_FN(stcat_conv_dgrad),
+    STCAT_PLAN_FN(stcat_weight_transpose),
+    STCAT_PLAN_FN(stcat_weight_transpose_multi),
+    STCAT_PLAN_FN(stcat_conv_wgrad),
+    STCAT_PLAN_FN(stcat_act_bwd),
+    STCAT_PLAN_FN(stcat_pos_sine_2d),
+    STCAT_PLAN_FN(stcat_sine_embed_fwd),
+    STCAT_PLAN_FN(stcat_sine_embed_bwd),
+    STCAT_PLAN_FN(stcat_linear_fwd),
+    STCAT_PLAN_FN(stcat_linear_dgrad),
+    STCAT_PLAN_FN(stcat_linear_fwd_acc),
+    STCAT_PLAN_FN(stcat_linear_dgrad_acc),
+    STCAT_PLAN_FN(stcat_linear_wgrad),
+    STCAT_PLAN_FN(stcat_small_linear_fwd),
+    STCAT_PLAN_FN(stcat_small_linear_bwd),
+    STCAT_PLAN_FN(stcat_colsum),
+    STCAT_PLAN_FN(stcat_layernorm_fwd),
+    STCAT_PLAN_FN(stcat_layernorm_bwd),
+    STCAT_PLAN_FN(stcat_ew),
+    STCAT_PLAN_FN(stcat_ew2d),
+    STCAT_PLAN_FN(stcat_stg_loss_fwd),
+    STCAT_PLAN_FN(stcat_stg_loss_bwd),
+    STCAT_PLAN_FN(stcat_dropout),
+    STCAT_PLAN_FN(stcat_mha_self_fwd),
+    STCAT_PLAN_FN(stcat_mha_self_bwd),
+    STCAT_PLAN_FN(stcat_mha_bs_fwd),
+    STCAT_PLAN_FN(stcat_mha_bs_bwd),
+    STCAT_PLAN_FN(stcat_attn_weights_mean),
+    STCAT_PLAN_FN(stcat_attn_q1_fwd),
+    STCAT_PLAN_FN(stcat_attn_q1_bwd),
+    STCAT_PLAN_FN(stcat_map2d_pool),
+    STCAT_PLAN_FN(stcat_map2d_cells),
+    STCAT_PLAN_FN(stcat_rowscale),
+    STCAT_PLAN_FN(stcat_grad_sqnorm),
+    STCAT_PLAN_FN(stcat_grad_clip_scale),
+    STCAT_PLAN_FN(stcat_ema_update),
+    STCAT_PLAN_FN(stcat_temporal_map_argmax),
+    STCAT_PLAN_FN(stcat_pl_conv_fwd),
+    STCAT_PLAN_FN(stcat_pl_conv_dgrad),
+    STCAT_PLAN_FN(stcat_pl_conv_wgrad),
+    STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),
+    STCAT_PLAN_FN(stcat_pl_split),
+    STCAT_PLAN_FN(stcat_pl_join),
+    STCAT_PLAN_FN(stcat_pl_act_bwd),
+    STCAT_PLAN_FN(stcat_pl_scale),
+    STCAT_PLAN_FN(stcat_weight_planes_multi),
+};
+constexpr int kPlanFns = (int)(sizeof(g_plan_fns) / sizeof(g_plan_fns[0]));
+inline stcat_plan::Plan* plan_of(void* h) { return static_cast<stcat_plan::Plan*>(h); }
+}  // namespace
+
+extern "C" {
+
+int stcat_plan_fn_index(const char* name) {
+  for (int i = 0; i < kPlanFns; ++i)
+    if (strcmp(g_plan_fns[i].name, name) == 0) return i;
+  return -1;
+}
+
+int stcat_plan_fn_nargs(int fn) { return (fn >= 0 && fn < kPlanFns) ? g_plan_fns[fn].nargs : -1; }
+
+void* stcat_plan_create(void) { return new stcat_plan::Plan(); }
+
+int stcat_plan_destroy(void* h) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl) return 0;
+#ifndef STCAT_EMU
+  for (void* e : pl->events)
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+#endif
+  delete pl;
+  return 0;
+}
+
+int stcat_plan_add_call(void* h, int fn, const unsigned long long* words, int nargs, int slot, int stream_arg) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || fn < 0 || fn >= kPlanFns) return fail("plan_add_call: unknown entry point %d", fn);
+  if (nargs != g_plan_fns[fn].nargs) return fail("plan_add_call: %s takes %d arguments, got %d", g_plan_fns[fn].name, g_plan_fns[fn].nargs, nargs);
+  if (slot < 0 || slot > 250 || stream_arg >= nargs) return fail("plan_add_call: bad stream slot / position");
+  stcat_plan::Op op = {};
+  op.kind = stcat_plan::OP_CALL; op.slot = (uint8_t)slot; op.fn = fn; op.arg0 = (uint32_t)pl->words.size(); op.nargs = nargs;
+  op.stream_arg = stream_arg;
+  for (int i = 0; i < nargs; ++i) pl->words.push_back((uint64_t)words[i]);
+  pl->ops.push_back(op);
+  if (slot + 1 > pl->n_slots) pl->n_slots = slot + 1;
+  return (int)op.arg0;   // index of the call's first argument word (relocations refer to it)
+}
+
+int stcat_plan_add_wait(void* h, int waiter_slot, int signal_slot) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || waiter_slot < 0 || signal_slot < 0 || waiter_slot > 250 || signal_slot > 250) return fail("plan_add_wait: bad slot");
+  stcat_plan::Op op = {};
+  op.kind = stcat_plan::OP_WAIT; op.slot = (uint8_t)waiter_slot; op.slot2 = (uint8_t)signal_slot;
+  op.arg0 = (uint32_t)pl->events.size();
+  pl->events.push_back(nullptr);
+  pl->ops.push_back(op);
+  const int m = (waiter_slot > signal_slot ? waiter_slot : signal_slot) + 1;
+  if (m > pl->n_slots) pl->n_slots = m;
+  return 0;
+}
+
+int stcat_plan_add_memset(void* h, void* ptr, unsigned long long bytes, int slot, int at_front) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || slot < 0 || slot > 250) return fail("plan_add_memset: bad slot");
+  stcat_plan::Op op = {};
+  op.kind = stcat_plan::OP_MEMSET; op.slot = (uint8_t)slot; op.arg0 = (uint32_t)pl->words.size();
+  pl->words.push_back((uint64_t)(uintptr_t)ptr);
+  pl->words.push_back((uint64_t)bytes);
+  if (at_front) pl->ops.insert(pl->ops.begin(), op); else pl->ops.push_back(op);
+  return (int)op.arg0;
+}
+
+int stcat_plan_add_yield(void* h, int tag) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl) return fail("plan_add_yield: no plan");
+  stcat_plan::Op op = {};
+  op.kind = stcat_plan::OP_YIELD; op.fn = tag;
+  pl->ops.push_back(op);
+  return 0;
+}
+
+int stcat_plan_add_reloc(void* h, int word, int ext, unsigned long long offset) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || word < 0 || (size_t)word >= pl->words.size() || ext < 0) return fail("plan_add_reloc: bad word / external index");
+  pl->relocs.push_back(stcat_plan::Reloc{(uint32_t)word, (uint32_t)ext, (uint64_t)offset});
+  if (ext + 1 > pl->n_ext) pl->n_ext = ext + 1;
+  return 0;
+}
+
+int stcat_plan_size(void* h, int* n_ops, int* n_words, int* n_relocs) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl) return fail("plan_size: no plan");
+  if (n_ops) *n_ops = (int)pl->ops.size();
+  if (n_words) *n_words = (int)pl->words.size();
+  if (n_relocs) *n_relocs = (int)pl->relocs.size();
+  return 0;
+}
+
+/* Replay ops [start, ...) of the plan: returns 0 with *next = -1 at the end of the plan, or 0 with *next = the op after
+ * a YIELD and *tag = its tag (the host does its part and calls again with start = *next).  ext[i]: this step's base
+ * address of external i (relocations are applied when start == 0); streams[s]: the hipStream_t of slot s. */
+int stcat_plan_run(void* h, const unsigned long long* ext, int n_ext, void* const* streams, int n_streams, int start,
+                   int* next, int* tag) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || !next) return fail("plan_run: no plan");
+  if (n_ext < pl->n_ext) return fail("plan_run: %d externals given, the plan relocates %d", n_ext, pl->n_ext);
+  if (n_streams < pl->n_slots) return fail("plan_run: %d streams given, the plan uses %d slots", n_streams, pl->n_slots);
+  uint64_t* w = pl->words.data();
+  if (start == 0) {
+    for (const stcat_plan::Reloc& r : pl->relocs) w[r.word] = (uint64_t)ext[r.ext] + r.off;
+    ++pl->replays;
+  }
+  const int n = (int)pl->ops.size();
+  for (int i = start; i < n; ++i) {
+    const stcat_plan::Op& op = pl->ops[i];
+    switch (op.kind) {
+      case stcat_plan::OP_CALL: {
+        if (op.stream_arg >= 0) w[op.arg0 + op.stream_arg] = (uint64_t)(uintptr_t)streams[op.slot];
+        const int rc = g_plan_fns[op.fn].call(w + op.arg0);
+        if (rc != 0) {
+          char inner[400];
+          snprintf(inner, sizeof(inner), "%s", g_err);
+          snprintf(g_err, sizeof(g_err), "plan op %d (%s): %s", i, g_plan_fns[op.fn].name, inner);
+          return rc;
+        }
+        break;
+      }
+      case stcat_plan::OP_WAIT: {
+#ifndef STCAT_EMU
+        if (streams[op.slot] == streams[op.slot2]) break;
+        hipEvent_t ev = (hipEvent_t)pl->events[op.arg0];
+        if (!ev) {
+          if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail("plan_run: event creation failed");
+          pl->events[op.arg0] = (void*)ev;
+        }
+        hipError_t e = hipEventRecord(ev, (hipStream_t)streams[op.slot2]);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)streams[op.slot], ev, 0);
+        if (e != hipSuccess) return fail("plan_run: stream wait failed at op %d: %s", i, hipGetErrorString(e));
+#endif
+        break;
+      }
+      case stcat_plan::OP_MEMSET: {
+        const hipError_t e = hipMemsetAsync((void*)(uintptr_t)w[op.arg0], 0, (size_t)w[op.arg0 + 1], (hipStream_t)streams[op.slot]);
+        if (e != hipSuccess) return fail("plan_run: memset failed at op %d", i);
+        break;
+      }
+      case stcat_plan::OP_YIELD:
+        *next = i + 1;
+        if (tag) *tag = op.fn;
+        return 0;
+    }
+  }
+  *next = -1;
+  return 0;
+}
+
+}  // extern "C"

@@ -71,12 +71,22 @@ def disable_zero_arena():
 
 
 def _zeros(like: torch.Tensor, *shape) -> torch.Tensor:
+    if L.RECORDER is not None:          # a launch plan is being recorded: its own chunks, cleared at the top of a replay
+        return L.RECORDER.zeros(shape)
     a = _ARENA.get(str(like.device))
     if a is not None:
         t = a.take(shape)
         if t is not None:
             return t
     return torch.zeros(shape, device=like.device, dtype=_f32)
+
+
+def _zero_take(like: torch.Tensor, shape) -> Optional[torch.Tensor]:
+    """a zeroed buffer that costs no fill launch (the recording plan's chunks, else the step's arena), or None"""
+    if L.RECORDER is not None:
+        return L.RECORDER.zeros(shape)
+    a = _ARENA.get(str(like.device))
+    return a.take(shape) if a is not None else None
 
 
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -104,6 +114,20 @@ FORK_ENABLED = not os.environ.get("STCAT_NO_FORK")  # two-stream decoders (Query
 GRAD_SINK = None  # dist.GradBucketReducer when gradients are exchanged: .early(params, grads) takes them mid-backward
 
 
+def _wait_stream(waiter, signal) -> None:
+    """waiter.wait_stream(signal); mirrored into the launch plan that is being recorded, if any"""
+    waiter.wait_stream(signal)
+    if L.RECORDER is not None:
+        L.RECORDER.wait(waiter, signal)
+
+
+def host_call(fn):
+    """run a host-side action that belongs at this point of a node's launch sequence (a launch plan replays it here)"""
+    if L.RECORDER is not None:
+        return L.RECORDER.host_call(fn)
+    return fn()
+
+
 class fork_stream:
     """`with fork_stream(x): ...` runs the body on a side stream ordered after everything queued so far on the
     current stream; `join(*outputs)` makes the current stream wait for it and tells the caching allocator that the
@@ -123,7 +147,7 @@ class fork_stream:
 
     def __enter__(self):
         if self.active:
-            self.side.wait_stream(self.main)
+            _wait_stream(self.side, self.main)
             self.ctx.__enter__()
         return self
 
@@ -134,7 +158,7 @@ class fork_stream:
 
     def join(self, *outputs):
         if self.active:
-            self.main.wait_stream(self.side)
+            _wait_stream(self.main, self.side)
             for t in outputs:
                 if torch.is_tensor(t):
                     t.record_stream(self.main)
@@ -199,8 +223,7 @@ def linear_fwd_raw(x2d, w, bias, res2d=None, relu=False, out=None, ldy=None, c_g
         # over grid.z with an atomic epilogue — 8 serial K-tiles on 4 workgroups are pure latency otherwise
         if (M <= 128 and K >= 128 and K % 64 == 0 and N % 64 == 0 and not relu and c_group == 0 and ldy is None
                 and L.get_mma_mode() != "f32" and x2d.is_contiguous()):
-            a = _ARENA.get(str(x2d.device))
-            out = a.take((M, N)) if a is not None else None
+            out = _zero_take(x2d, (M, N))
             if out is not None:
                 L.call("stcat_linear_fwd_acc", x2d.data_ptr(), w.data_ptr(), L._ptr(bias), L._ptr(res2d), out.data_ptr(), M, N, K,
                        K, N, (res2d.stride(0) if res2d is not None else 0), L.stream_of(x2d))
@@ -668,6 +691,8 @@ def dropout_forward_started() -> None:
 def dropout_backward_done() -> None:
     """called by the last backward node of the path (encoder, then backbone): the slot may be reused by the next step"""
     _dropout_stream.pending = False
+    if L.RECORDER is not None:
+        L.RECORDER.effect(dropout_backward_done)
 
 
 def dropout_stream_state():
@@ -1267,7 +1292,7 @@ class WeightPlanes:
         state = (WEIGHT_EPOCH, tuple(w._version for w in weights))
         # (while a hipGraph is being captured the launch must be part of it: the replayed step follows an optimizer
         # step that moved the fp32 weights — ADVICE r02)
-        capturing = weights[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        capturing = (weights[0].is_cuda and torch.cuda.is_current_stream_capturing()) or L.RECORDER is not None
         if state != self.state or capturing:
             L.call("stcat_weight_planes_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
             self.state = state
@@ -1295,7 +1320,7 @@ class WgradStream:
 
     def __enter__(self):
         if self.active:
-            self.side.wait_stream(self.main)
+            _wait_stream(self.side, self.main)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -1314,7 +1339,7 @@ class WgradStream:
 
     def join(self, *outputs):
         if self.active:
-            self.main.wait_stream(self.side)
+            _wait_stream(self.main, self.side)
             for t in outputs:
                 if torch.is_tensor(t):
                     t.record_stream(self.main)

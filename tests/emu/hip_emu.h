@@ -43,6 +43,8 @@ static inline hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStr
   return hipSuccess;
 }
 
+typedef void* hipEvent_t;
+
 extern "C" void stcat_emu_switch(void** from_sp, void* to_sp);
 
 namespace emu {

@@ -39,9 +39,17 @@ def _dispatcher_ops(dev, big):
     gd = gy.permute(0, 2, 3, 1).contiguous().to(dev)
     close(S.conv_dgrad(gd, wd, list(xd.shape), 1, 1, None, None, None).permute(0, 3, 1, 2), xr.grad, 2e-4, "conv_dgrad")
     close(S.conv_wgrad(gd, xd, list(wd.shape), 1, 1).permute(0, 3, 1, 2), wr.grad, 2e-4, "conv_wgrad")
-    # the plane-format form of the same conv
-    yp = S.conv_bn_act_fwd_planes(S.planes_split(xd), S.planes_split(wd), sc.to(dev), bi.to(dev), None, 1, 1, True)
-    close(S.planes_join(yp).permute(0, 3, 1, 2), y_ref, 2e-4, "dispatcher conv_bn_act_fwd_planes")
+    # the plane-format form of the same conv: two bf16 planes per tensor (mode bf16x3p), three (mode bf16x6p)
+    from stcat_amd import _lib
+    for mode, np_ in (("bf16x3p", 2), ("bf16x6p", 3)):
+        _lib.set_mma_mode(mode)
+        try:
+            xp = S.planes_split(xd)
+            assert xp.shape[0] == np_ and xp.dtype == torch.bfloat16
+            yp = S.conv_bn_act_fwd_planes(xp, S.planes_split(wd), sc.to(dev), bi.to(dev), None, 1, 1, True)
+            close(S.planes_join(yp).permute(0, 3, 1, 2), y_ref, 2e-4, f"dispatcher conv_bn_act_fwd_planes {mode}")
+        finally:
+            _lib.set_mma_mode("f32")
     close(S.maxpool3x3s2_fwd(xd).permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1), 1e-6, "maxpool")
     # linear (+ backward), LayerNorm (+ backward)
     M, K, N = 70, 256, 128
