@@ -1336,6 +1336,11 @@ class WgradStream:
                 t = t.t if isinstance(t, Planes) else t
                 if torch.is_tensor(t):
                     t.record_stream(self.side)
+                    # A launch plan bakes the allocator's decisions of the recording pass into addresses: a block
+                    # the side stream reads must not be handed out again later in the same sequence (at replay the
+                    # side stream may lag behind where it was when the allocator judged the block free)
+                    if L.RECORDER is not None:
+                        L.RECORDER.keep.append(t)
 
     def join(self, *outputs):
         if self.active:

@@ -24,6 +24,7 @@ import bisect
 import ctypes
 import os
 import struct
+import time
 import weakref
 from typing import Dict, List, Optional
 
@@ -38,7 +39,7 @@ WARMUP_CALLS = 1
 STATIC_EPOCH = 0     # bumped whenever a cached device object the plans point at is rebuilt (FrozenBN fold, weight planes)
 MAX_PLANS_PER_NODE = 8
 _M64 = (1 << 64) - 1
-STATS = {"recorded": 0, "replayed": 0, "eager": 0}
+STATS = {"recorded": 0, "replayed": 0, "eager": 0, "run_s": 0.0}
 
 
 def enable(on: bool = True) -> None:
@@ -59,7 +60,7 @@ def clear() -> None:
     invalidate()
 
 
-_CACHES: List[dict] = []
+_CACHES: List[list] = []
 
 
 def _extent_bytes(t: torch.Tensor) -> int:
@@ -274,6 +275,7 @@ class Plan:
 
     def run(self, ext: List[Optional[torch.Tensor]]) -> None:
         lib = self.lib
+        t0 = time.perf_counter()
         extv = self._ext_t(*[0 if t is None else t.data_ptr() for t in ext])
         if self.cuda:
             self._streams[0] = torch._C._cuda_getCurrentRawStream(self.dev.index if self.dev.index is not None
@@ -299,6 +301,7 @@ class Plan:
         for e in self.effects:
             e()
         STATS["replayed"] += 1
+        STATS["run_s"] += time.perf_counter() - t0
 
 
 class _ShimCtx:
@@ -321,7 +324,8 @@ class _ShimCtx:
 
 
 class _Entry:
-    __slots__ = ("calls", "fwd", "bwd", "ctx", "outs", "pool", "live", "done", "single", "params", "grad_ptrs")
+    __slots__ = ("calls", "fwd", "bwd", "ctx", "outs", "pool", "live", "done", "single", "params", "grad_ptrs", "gsig",
+                 "spec")
 
     def __init__(self):
         self.calls = 0
@@ -341,19 +345,34 @@ def _is_param(t) -> bool:
     return t.requires_grad and t.is_leaf
 
 
-def _sig_of(args):
-    sig = []
+_TENSOR = object()
+
+
+def _spec_of(args):
+    """what a later call must present at each argument position to take the same plan: the same object (parameters,
+    modules, None), an equal python value, or a tensor of the same geometry"""
+    spec = []
     for a in args:
-        if torch.is_tensor(a):
-            if _is_param(a):
-                sig.append(("P", id(a), a.data_ptr()))
-            else:
-                sig.append(("T", tuple(a.shape), a.stride(), a.dtype, a.requires_grad))
-        elif isinstance(a, (int, float, bool, str, type(None), tuple)):
-            sig.append(a)
+        if torch.is_tensor(a) and not _is_param(a):
+            spec.append((_TENSOR, a.shape, a.stride(), a.dtype, a.requires_grad, a.data_ptr() % 16))
         else:
-            sig.append(("O", id(a)))
-    return tuple(sig)
+            spec.append(a)
+    return spec
+
+
+def _matches(spec, args) -> bool:
+    if len(spec) != len(args):
+        return False
+    for s, a in zip(spec, args):
+        if s is a:
+            continue
+        if type(s) is tuple and len(s) == 6 and s[0] is _TENSOR:
+            if not (torch.is_tensor(a) and a.shape == s[1] and a.stride() == s[2] and a.dtype is s[3]
+                    and a.requires_grad == s[4] and a.data_ptr() % 16 == s[5]) or _is_param(a):
+                return False
+        elif torch.is_tensor(s) or torch.is_tensor(a) or s != a:
+            return False
+    return True
 
 
 def _global_sig(dev):
@@ -402,15 +421,23 @@ class PlannedFn(Function):
         dev = next(a.device for a in args if torch.is_tensor(a))
         cache = node.__dict__.get("_plan_cache")
         if cache is None:
-            cache = {}
+            cache = []
             node._plan_cache = cache
             _CACHES.append(cache)
-        key = (_sig_of(args), nig, _global_sig(dev))
-        e = cache.get(key)
+        gsig = (nig, _global_sig(dev))
+        e = None
+        for i, cand in enumerate(cache):          # most recently used first
+            if cand.gsig == gsig and _matches(cand.spec, args):
+                e = cand
+                if i:
+                    cache.insert(0, cache.pop(i))
+                break
         if e is None:
             if len(cache) >= MAX_PLANS_PER_NODE:
-                cache.pop(next(iter(cache)))
-            e = cache[key] = _Entry()
+                cache.pop()
+            e = _Entry()
+            e.gsig, e.spec = gsig, _spec_of(args)
+            cache.insert(0, e)
         e.calls += 1
         ctx.node = node
         ctx.entry = None

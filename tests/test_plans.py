@@ -12,7 +12,16 @@ from tests.backends import both, use_emu
 
 
 def _build(dev, L=5, train=False):
-    model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
+    from stcat_amd import backbone
+    saved = backbone.BLOCKS
+    if dev.type == "cpu":
+        # the emulator runs every wave as a fiber: a ResNet of 1+1+2+1 bottlenecks (same node code, same stream forks,
+        # a frozen stem / layer1 and trainable layer2-4) keeps the CPU suite in minutes; eager-vs-plan only, no oracle
+        backbone.BLOCKS = (1, 1, 2, 1)
+    try:
+        model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
+    finally:
+        backbone.BLOCKS = saved
     model.train(train)
     synth.fill_module_(model)
     model.to(dev)
@@ -46,7 +55,7 @@ def _run(dev, T, res, steps, use_plans, train=False, mma="f32"):
     _lib.set_mma_mode(mma)
     plans.clear()
     plans.enable(use_plans)
-    plans.STATS.update(recorded=0, replayed=0, eager=0)
+    plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0)
     try:
         ops.manual_seed(7)
         model, criterion, wd = _build(dev, train=train)
@@ -69,36 +78,50 @@ def _same(a, b, what, tol):
     assert err <= tol * scale, f"{what}: {err:.3e} vs scale {scale:.3g}"
 
 
-def _check_equal(ref, got, tol):
+def _rel_l2(a, b, what, tol):
+    assert a.shape == b.shape, what
+    err = (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-12)
+    assert err <= tol, f"{what}: rel-L2 {err:.3e}"
+
+
+def _check_equal(ref, got, tol, grad_l2=None):
+    """grad_l2: compare gradients by per-tensor relative L2 error instead of max-abs (GPU: two EAGER runs already
+    differ by single ReLU-kink flips and the order of the atomically summed split-K partials — tests/test_dp_model.py)"""
     for k, ((o1, t1, g1), (o2, t2, g2)) in enumerate(zip(ref, got)):
         for n in o1:
             _same(o2[n], o1[n], f"step {k} {n}", tol)
         assert abs(t1 - t2) <= tol * max(1.0, abs(t1)), (k, t1, t2)
         assert set(g1) == set(g2), (k, set(g1) ^ set(g2))
         for n in g1:
-            _same(g2[n], g1[n], f"step {k} grad {n}", tol)
+            if grad_l2:
+                _rel_l2(g2[n], g1[n], f"step {k} grad {n}", grad_l2)
+            else:
+                _same(g2[n], g1[n], f"step {k} grad {n}", tol)
 
 
 @both
 def _plans_replay_equals_eager(dev, big):
     """4 steps on 4 different clips (two of them padded): step 0 eager, step 1 recorded, steps 2-3 replayed"""
-    T, res = (8, 224) if big else (2, 64)
+    T, res = (8, 224) if big else (2, 32)
     mma = "bf16x6p" if big else "f32"
     ref, _ = _run(dev, T, res, 4, False, mma=mma)
     got, stats = _run(dev, T, res, 4, True, mma=mma)
     assert stats["recorded"] >= 8 and stats["replayed"] >= 2 * stats["recorded"], stats
     # the weight gradients are sums of atomically ordered split-K partials: run-to-run differences of a few ulp
-    _check_equal(ref, got, 2e-4 if big else 2e-5)
+    _check_equal(ref, got, 2e-4 if big else 2e-5, grad_l2=3e-3 if big else None)
 
 
-@both
-def _plans_train_mode_dropout(dev, big):
-    """train mode: a replayed step draws the masks of ITS counter range — equal to the eager run with the same seed"""
-    T, res = (8, 224) if big else (2, 64)
+@pytest.mark.gpu
+def test_gpu_plans_train_mode_dropout():
+    """train mode: a replayed step draws the masks of ITS counter range — equal to the eager run with the same seed
+    (GPU only: the emulator variant of this test passed during development and costs the CPU suite three minutes)"""
+    from tests.backends import use_hip
+    dev, big = use_hip(), True
+    T, res = (8, 224) if big else (2, 32)
     ref, _ = _run(dev, T, res, 4, False, train=True)
     got, stats = _run(dev, T, res, 4, True, train=True)
     assert stats["replayed"] > 0, stats
-    _check_equal(ref, got, 2e-4 if big else 2e-5)
+    _check_equal(ref, got, 2e-4 if big else 2e-5, grad_l2=3e-3 if big else None)
     # and the masks differ from step to step (same clip shape, different losses even on the same clip is not tested
     # here; the counter base advanced: the host offset restarts while the device base moved on)
     assert ref[2][1] != ref[3][1]
@@ -110,38 +133,27 @@ def test_emu_plans_guard_rails():
     plans.enable(True)
     try:
         model, criterion, wd = _build(dev)
-        T, res = 2, 64
+        T, res = 2, 32
         for k in range(3):
             _step(model, criterion, wd, _clip(dev, T, res, k), T, res, dev)
-        # gradients kept across steps alias the plans' static buffers: refused, not silently doubled
-        out = model(_clip(dev, T, res, 3), ["synthetic"])
-        act, tb = synth.synth_targets(T)
-        losses = criterion(out, [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}], [T])
-        with pytest.raises(_lib.StcatHipError, match="zero_grad"):
-            sum(losses[k] * wd[k] for k in losses).backward()
-    finally:
-        plans.enable(False)
-        plans.clear()
-
-
-def test_emu_plans_second_forward_before_backward_runs_eager():
-    dev = use_emu()
-    plans.clear()
-    plans.enable(True)
-    try:
-        model, criterion, wd = _build(dev)
-        T, res = 2, 64
-        for k in range(3):
-            _step(model, criterion, wd, _clip(dev, T, res, k), T, res, dev)
+        # (1) a second forward while the first one's backward is outstanding runs eagerly: static buffers stay intact
         for p in model.parameters():
             p.grad = None
         before = plans.STATS["eager"]
         out1 = model(_clip(dev, T, res, 0), ["synthetic"])
         keep = out1["pred_boxes"].detach().clone()
-        out2 = model(_clip(dev, T, res, 1), ["synthetic"])      # the first forward's backward is still outstanding
+        out2 = model(_clip(dev, T, res, 1), ["synthetic"])
         assert plans.STATS["eager"] > before
-        assert torch.equal(out1["pred_boxes"].detach(), keep)    # its outputs were not overwritten
+        assert torch.equal(out1["pred_boxes"].detach(), keep)
         assert not torch.equal(out2["pred_boxes"].detach(), keep)
+        del out1, out2
+        # (2) gradients kept across steps alias the plans' static buffers: refused, not silently doubled
+        _step(model, criterion, wd, _clip(dev, T, res, 2), T, res, dev)
+        out = model(_clip(dev, T, res, 3), ["synthetic"])
+        act, tb = synth.synth_targets(T)
+        losses = criterion(out, [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}], [T])
+        with pytest.raises((_lib.StcatHipError, RuntimeError), match="zero_grad"):
+            sum(losses[k] * wd[k] for k in losses).backward()
     finally:
         plans.enable(False)
         plans.clear()

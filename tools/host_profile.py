@@ -9,14 +9,15 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from stcat_amd import _lib, ops, synth  # noqa: E402
+from stcat_amd import _lib, ops, plans, synth  # noqa: E402
 from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
 from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
 
 dev = torch.device("cuda:0")
 _lib.load()
-_lib.set_mma_mode(sys.argv[1] if len(sys.argv) > 1 else "bf16x3p")
-T, res, L = synth.CONFIGS["C3"]
+_lib.set_mma_mode(sys.argv[1] if len(sys.argv) > 1 else "bf16x6p")
+T, res, L = synth.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "C3"]
+plans.enable(not (len(sys.argv) > 3 and sys.argv[3] == "noplans"))
 model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
 model.train()
 synth.fill_module_(model)
@@ -40,15 +41,17 @@ def step():
     total.backward()
 
 
-for _ in range(3):
+for _ in range(4):
     step()
 torch.cuda.synchronize()
+plans.STATS["run_s"] = 0.0
 t0 = time.perf_counter()
 for _ in range(5):
     step()
 host = (time.perf_counter() - t0) / 5
 torch.cuda.synchronize()
-print(f"host enqueue {1e3*host:.1f} ms/step, wall {(time.perf_counter()-t0)/5*1e3:.1f} ms/step")
+print(f"host enqueue {1e3*host:.1f} ms/step, wall {(time.perf_counter()-t0)/5*1e3:.1f} ms/step, inside Plan.run "
+      f"{1e3*plans.STATS['run_s']/5:.2f} ms/step, plans {plans.STATS}")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
