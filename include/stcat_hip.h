@@ -258,6 +258,12 @@ int stcat_map2d_pool(const float* x, float* pooled, int b, int T, int N, int D, 
  * of the caller-zeroed NHWC map [b,N,N,D] = max over pooled[b, cell_i .. cell_j, :] */
 int stcat_map2d_cells(const float* pooled, const int* cell_i, const int* cell_j, int ncells, float* map, int b, int N, int D,
                       void* stream);
+/* backward of the two launches above (train mode returns raw scores, map2d_head.py:122-124): a cell's gradient goes to
+ * the first maximum of its range [i, j] (where the reference's cascade of MaxPool1d backward passes routes it), then
+ * through the adaptive pooling (:48-51); dpooled [b,N,D] and dx [b,T,D] are zeroed by the caller (atomic accumulation) */
+int stcat_map2d_cells_bwd(const float* pooled, const int* cell_i, const int* cell_j, int ncells, const float* dmap,
+                          float* dpooled, int b, int N, int D, void* stream);
+int stcat_map2d_pool_bwd(const float* x, const float* dpooled, float* dx, int b, int T, int N, int D, void* stream);
 /* y[m, :] *= w[m % period]: the per-pixel mask-normalisation weight after each conv + ReLU (:247-249) */
 int stcat_rowscale(float* y, const float* w, long rows, int C, int period, void* stream);
 
@@ -328,8 +334,11 @@ int stcat_plan_destroy(void* plan);
 int stcat_plan_add_call(void* plan, int fn, const unsigned long long* words, int nargs, int stream_slot, int stream_arg);
 /* everything issued later on `waiter_slot` waits for what is queued on `signal_slot` at this point of the replay */
 int stcat_plan_add_wait(void* plan, int waiter_slot, int signal_slot);
-/* zero `bytes` at ptr (the plan's accumulation buffers); at_front: before every other op; returns the pointer's word */
+/* zero `bytes` at ptr (the plan's accumulation buffers) at this point of the sequence (at_front: before every other
+ * op); returns the pointer's word, the byte count is the word after it */
 int stcat_plan_add_memset(void* plan, void* ptr, unsigned long long bytes, int stream_slot, int at_front);
+/* overwrite one argument word (the byte count of a memset whose extent is only known when the recording ends) */
+int stcat_plan_set_word(void* plan, int word, unsigned long long value);
 /* the replay returns to the host here (tag identifies the host-side action), to be resumed at *next */
 int stcat_plan_add_yield(void* plan, int tag);
 int stcat_plan_add_reloc(void* plan, int word, int external, unsigned long long byte_offset);

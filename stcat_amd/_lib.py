@@ -56,6 +56,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_attn_q1_bwd": "pppppppppppp" + "iiiiiif" + "fllps",
     "stcat_map2d_pool": "ppiiiis",
     "stcat_map2d_cells": "pppipiiis",
+    "stcat_map2d_cells_bwd": "pppippiiis",
+    "stcat_map2d_pool_bwd": "pppiiiis",
     "stcat_rowscale": "pplii" + "s",
     "stcat_grad_sqnorm": "pppiips",
     "stcat_adamw_ema_step": "pppiipPPifffiffs",
@@ -87,6 +89,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_plan_add_call": "PiPiii",
     "stcat_plan_add_wait": "Pii",
     "stcat_plan_add_memset": "Ppuii",
+    "stcat_plan_set_word": "Piu",
     "stcat_plan_add_yield": "Pi",
     "stcat_plan_add_reloc": "Piiu",
     "stcat_plan_size": "PPPP",

@@ -290,6 +290,232 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The same three kernels for 256 < S <= 512 tokens per frame: non-square clips.  The reference's transforms resize the
+// short side to 448 with max_size 720 (datasets/build.py:20-44): a 16:9 video becomes 405 x 720 -> 13 x 23 visual tokens
+// + text + [CLS] = 310..340 rows (modal_encoder.py:161-168).  K / V (resp. Q / dO) of the (frame, head) still fit the
+// CU's LDS (<= 135 KB, dynamic); a workgroup is 8 waves = 8 query (key) tiles and grid.y walks the tile groups.  The
+// forward keeps softmax exact without 16 score tiles in registers by running the key tiles twice: pass 1 = running
+// max / sum (online), pass 2 = recompute the scores, normalise, stash Pt, accumulate P V.
+// ---------------------------------------------------------------------------------
+static __device__ __forceinline__ void stcat_attn_stage2(const float* Ag, int lda, const float* Bg, int ldb, float* As,
+                                                         int a_ld, float* Bs, int S, int SP, int t, int nthreads) {
+  // As [SP][a_ld] (a_ld = 33: conflict-free column reads; 32: row-major B operand), Bs [SP][32]; rows >= S are zero
+  for (int i = t; i < SP * 8; i += nthreads) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
+    if (row < S) {
+      av = stcat_ld4(Ag + (long)row * lda + c4);
+      bv = stcat_ld4(Bg + (long)row * ldb + c4);
+    }
+    float* ad = &As[row * a_ld + c4];
+    ad[0] = av.x; ad[1] = av.y; ad[2] = av.z; ad[3] = av.w;
+    stcat_st4(&Bs[row * 32 + c4], bv);
+  }
+}
+
+__global__ void __launch_bounds__(512) mha_self_fwd_long_kernel(AttnParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int KLD = 33;
+  const int NT = (p.S + 31) >> 5, SP = NT * 32;
+  STCAT_DYN_SHARED(float, sm);
+  float* Ks = sm;
+  float* Vs = Ks + SP * KLD;
+  float* kb = Vs + SP * 32;
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+  const int qt = blockIdx.y * 8 + (t >> 6);
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  stcat_attn_stage2(p.K + (long)b * p.S * p.ldk + h * 32, p.ldk, p.V + (long)b * p.S * p.ldv + h * 32, p.ldv, Ks, KLD, Vs,
+                    p.S, SP, t, 512);
+  for (int i = t; i < SP; i += 512)
+    kb[i] = (i < p.S && !(p.kpm && p.kpm[(long)b * p.S + i])) ? 0.f : STCAT_NEG_INF;
+  const int q = qt * 32 + l31;
+  float qr[16];
+  {
+    const float* Qg = p.Q + ((long)b * p.S + q) * p.ldq + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 v4 = q < p.S ? stcat_ld4(Qg + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qr[c * 4 + 0] = v4.x * p.scale; qr[c * 4 + 1] = v4.y * p.scale;
+      qr[c * 4 + 2] = v4.z * p.scale; qr[c * 4 + 3] = v4.w * p.scale;
+    }
+  }
+  __syncthreads();
+  if (qt >= NT) return;
+  // pass 1: this lane's 16 keys of every tile -> running (max, sum); the lane pair (l31, l31 + 32) is merged afterwards
+  float mx = STCAT_NEG_INF, sum = 0.f;
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x16 sc;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s) sc = STCAT_MFMA_32x32x2(Ks[(kt * 32 + l31) * KLD + hi * 16 + s], qr[s], sc);
+    float tm = STCAT_NEG_INF;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      sc[r] += kb[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+      tm = fmaxf(tm, sc[r]);
+    }
+    const float mn = fmaxf(mx, tm);
+    if (mn > STCAT_NEG_INF) {
+      float ts = 0.f;
+      STCAT_UNROLL
+      for (int r = 0; r < 16; ++r) ts += __expf(sc[r] - mn);
+      sum = sum * __expf(mx - mn) + ts;
+      mx = mn;
+    }
+  }
+  {
+    const float mo = __shfl_xor(mx, 32), so = __shfl_xor(sum, 32);
+    const float mn = fmaxf(mx, mo);
+    sum = (mx > STCAT_NEG_INF ? sum * __expf(mx - mn) : 0.f) + (mo > STCAT_NEG_INF ? so * __expf(mo - mn) : 0.f);
+    mx = mn;
+  }
+  const float inv = 1.f / sum;
+  float* Ptg = p.Pt + (long)blockIdx.x * SP * SP;
+  f32x16 o;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x16 sc;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s) sc = STCAT_MFMA_32x32x2(Ks[(kt * 32 + l31) * KLD + hi * 16 + s], qr[s], sc);
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = __expf(sc[r] + kb[key] - mx) * inv;
+      if (p.Pt) Ptg[(long)key * SP + q] = pr;
+      const float pd = pr * stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      o = STCAT_MFMA_32x32x2(pd, Vs[key * 32 + l31], o);
+    }
+  }
+  float* Og = p.O + (long)b * p.S * p.ldo + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (qq < p.S) Og[(long)qq * p.ldo] = o[r];
+  }
+}
+
+__global__ void __launch_bounds__(512) mha_self_bwd_dq_long_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int KLD = 33;
+  const int NT = (p.S + 31) >> 5, SP = NT * 32;
+  STCAT_DYN_SHARED(float, sm);
+  float* Vs = sm;              // [SP][33]: A operand of dP^T = V dO^T
+  float* Ks = Vs + SP * KLD;   // [SP][32]: B operand of dQ = dS K
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+  const int qt = blockIdx.y * 8 + (t >> 6);
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  stcat_attn_stage2(p.V + (long)b * p.S * p.ldv + h * 32, p.ldv, p.K + (long)b * p.S * p.ldk + h * 32, p.ldk, Vs, KLD, Ks,
+                    p.S, SP, t, 512);
+  const int q = qt * 32 + l31;
+  float dor[16];
+  float delta = 0.f;
+  {
+    const float* g = p.dO + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    const float* og = p.O + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = v4;
+      if (q < p.S) {
+        v4 = stcat_ld4(g + c * 4);
+        o4 = stcat_ld4(og + c * 4);
+      }
+      dor[c * 4 + 0] = v4.x; dor[c * 4 + 1] = v4.y; dor[c * 4 + 2] = v4.z; dor[c * 4 + 3] = v4.w;
+      delta += v4.x * o4.x + v4.y * o4.y + v4.z * o4.z + v4.w * o4.w;
+    }
+  }
+  delta += __shfl_xor(delta, 32);
+  if (p.dW && q < p.S) delta += p.corr[(long)blockIdx.x * p.S + q];
+  __syncthreads();
+  if (qt >= NT) return;
+  const float* Ptg = p.Pt + (long)blockIdx.x * SP * SP + (long)hi * 4 * SP + q;
+  float* dStg = p.dSt + (long)blockIdx.x * SP * SP + (long)hi * 4 * SP + q;
+  const float invH = 1.f / (float)p.H;
+  f32x16 dq;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x16 dp;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s) dp = STCAT_MFMA_32x32x2(Vs[(kt * 32 + l31) * KLD + hi * 16 + s], dor[s], dp);
+    float pr_[16];
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) pr_[r] = Ptg[(long)(kt * 32 + (r & 3) + 8 * (r >> 2)) * SP];
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int krel = kt * 32 + (r & 3) + 8 * (r >> 2);
+      const int key = krel + 4 * hi;
+      float dpv = dp[r];
+      if (p.dW && q < p.S && key < p.S) dpv += p.dW[((long)b * p.S + q) * p.S + key] * invH;
+      dpv *= stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      const float ds = pr_[r] * (dpv - delta) * p.scale;
+      dStg[(long)krel * SP] = ds;
+      dq = STCAT_MFMA_32x32x2(ds, Ks[key * 32 + l31], dq);
+    }
+  }
+  float* g = p.dQ + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (qq < p.S) g[(long)qq * p.ldg] = dq[r];
+  }
+}
+
+__global__ void __launch_bounds__(512) mha_self_bwd_dkv_long_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
+  const int NT = (p.S + 31) >> 5, SP = NT * 32;
+  STCAT_DYN_SHARED(float, sm);
+  float* dOs = sm;             // [SP][32]
+  float* Qs = dOs + SP * 32;   // [SP][32]
+  const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+  const int kt = blockIdx.y * 8 + (t >> 6);
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  stcat_attn_stage2(p.dO + (long)b * p.S * p.ldo + h * 32, p.ldo, p.Q + (long)b * p.S * p.ldq + h * 32, p.ldq, dOs, 32, Qs,
+                    p.S, SP, t, 512);
+  __syncthreads();
+  if (kt >= NT) return;
+  const int key = kt * 32 + l31;
+  const float* Prow = p.Pt + (long)blockIdx.x * SP * SP + (long)key * SP + hi * 4;
+  const float* Srow = p.dSt + (long)blockIdx.x * SP * SP + (long)key * SP + hi * 4;
+  f32x16 dv, dk;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+  for (int qc = 0; qc < SP / 8; ++qc) {
+    float4 pv = stcat_ld4(Prow + qc * 8);
+    const float4 sv = stcat_ld4(Srow + qc * 8);
+    const int qb = qc * 8 + hi * 4;
+    if (p.drop.thresh) {
+      const unsigned long long c0 = ((unsigned long long)blockIdx.x * SP + key) * SP + qb;
+      pv.x *= stcat_drop_mul(p.drop, c0); pv.y *= stcat_drop_mul(p.drop, c0 + 1);
+      pv.z *= stcat_drop_mul(p.drop, c0 + 2); pv.w *= stcat_drop_mul(p.drop, c0 + 3);
+    }
+    dv = STCAT_MFMA_32x32x2(pv.x, dOs[(qb + 0) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.x, Qs[(qb + 0) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.y, dOs[(qb + 1) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.y, Qs[(qb + 1) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.z, dOs[(qb + 2) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.z, Qs[(qb + 2) * 32 + l31], dk);
+    dv = STCAT_MFMA_32x32x2(pv.w, dOs[(qb + 3) * 32 + l31], dv);
+    dk = STCAT_MFMA_32x32x2(sv.w, Qs[(qb + 3) * 32 + l31], dk);
+  }
+  float* gv = p.dV + (long)b * p.S * p.ldgv + h * 32 + l31;
+  float* gk = p.dK + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (kk < p.S) {
+      gv[(long)kk * p.ldgv] = dv[r];
+      gk[(long)kk * p.ldg] = dk[r];
+    }
+  }
+}
+
 // head-averaged attention weights W[b][q][k] = mean_h P[b][h][q][k]  (nn.MultiheadAttention
 // need_weights=True; consumed only for the time decoder: pipeline.py:84-85)
 __global__ void attn_weights_mean_kernel(const float* Pt, float* W, int B, int H, int S, int SP, DropParams drop) {
@@ -357,14 +583,17 @@ struct AttnQ1Params {
   DropParams drop;  // counter = bh * S + s; P keeps the undropped softmax
 };
 
-#define STCAT_Q1_MAXC 4  // S <= 256
+#define STCAT_Q1_MAXC 4  // key chunks of 256: S <= 1024
 
-// One workgroup per (frame, head); its four waves take 64 keys each (S <= 256), so 4x as many waves are in flight
+// One workgroup per (frame, head); its four waves take 64 keys each per 256-key chunk, so 4x as many waves are in flight
 // as with one wave per (frame, head) — the kernel is a latency-bound gather of 128-byte key / value rows
-// (3 x 13.5 MB per layer at C3), and memory-level parallelism is what it needs.
+// (3 x 13.5 MB per layer at C3), and memory-level parallelism is what it needs.  NC = number of 256-key chunks: the
+// square benchmark clips (S' = 206) are NC = 1; a 405 x 720 clip of the reference's transforms (datasets/build.py:20-44:
+// 13 x 23 + text tokens = 310..340 keys) is NC = 2.  A lane keeps its NC scores in registers: softmax stays single-pass.
+template <int NC>
 __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
   p.drop = stcat_drop_resolve(p.drop);
-  __shared__ float ps[STCAT_Q1_MAXC * 64];
+  __shared__ float ps[NC * 256];
   __shared__ float red[2][4];
   __shared__ float opart[4][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -377,52 +606,71 @@ __global__ void __launch_bounds__(256) attn_q1_fwd_kernel(AttnQ1Params p) {
     float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
   }
-  const int s = w * 64 + lane;
-  float val = STCAT_NEG_INF;
-  if (s < p.S && !(p.kpm && p.kpm[(long)b * p.S + s])) {
-    const float* kr = p.k1 + ((long)b * p.S + s) * p.ldk + h * 32;
-    float dot = 0.f;
-    STCAT_UNROLL
-    for (int d4 = 0; d4 < 8; ++d4) {
-      float4 kv = stcat_ld4(kr + d4 * 4);
-      dot += kv.x * qa[d4 * 4] + kv.y * qa[d4 * 4 + 1] + kv.z * qa[d4 * 4 + 2] + kv.w * qa[d4 * 4 + 3];
-    }
-    if (p.k2) {
-      const float* kr2 = p.k2 + ((long)b * p.S + s) * p.ldk + h * 32;
+  float val[NC];
+  float mloc = STCAT_NEG_INF;
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s = ch * 256 + w * 64 + lane;
+    val[ch] = STCAT_NEG_INF;
+    if (s < p.S && !(p.kpm && p.kpm[(long)b * p.S + s])) {
+      const float* kr = p.k1 + ((long)b * p.S + s) * p.ldk + h * 32;
+      float dot = 0.f;
       STCAT_UNROLL
       for (int d4 = 0; d4 < 8; ++d4) {
-        float4 kv = stcat_ld4(kr2 + d4 * 4);
-        dot += kv.x * qb[d4 * 4] + kv.y * qb[d4 * 4 + 1] + kv.z * qb[d4 * 4 + 2] + kv.w * qb[d4 * 4 + 3];
+        float4 kv = stcat_ld4(kr + d4 * 4);
+        dot += kv.x * qa[d4 * 4] + kv.y * qa[d4 * 4 + 1] + kv.z * qa[d4 * 4 + 2] + kv.w * qa[d4 * 4 + 3];
       }
+      if (p.k2) {
+        const float* kr2 = p.k2 + ((long)b * p.S + s) * p.ldk + h * 32;
+        STCAT_UNROLL
+        for (int d4 = 0; d4 < 8; ++d4) {
+          float4 kv = stcat_ld4(kr2 + d4 * 4);
+          dot += kv.x * qb[d4 * 4] + kv.y * qb[d4 * 4 + 1] + kv.z * qb[d4 * 4 + 2] + kv.w * qb[d4 * 4 + 3];
+        }
+      }
+      val[ch] = dot * p.scale;
     }
-    val = dot * p.scale;
+    mloc = fmaxf(mloc, val[ch]);
   }
-  const float mw = stcat_wave_max(val);
+  const float mw = stcat_wave_max(mloc);
   if (lane == 0) red[0][w] = mw;
   __syncthreads();
   const float mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-  const float e = __expf(val - mx);
-  const float sw = stcat_wave_sum(e);
+  float esum = 0.f;
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    val[ch] = __expf(val[ch] - mx);
+    esum += val[ch];
+  }
+  const float sw = stcat_wave_sum(esum);
   if (lane == 0) red[1][w] = sw;
   __syncthreads();
   const float inv = 1.f / (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-  const float pr = e * inv;
-  ps[s] = pr * stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
-  if (s < p.S) p.P[(long)bh * p.S + s] = pr;
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s = ch * 256 + w * 64 + lane;
+    const float pr = val[ch] * inv;
+    ps[s] = pr * stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
+    if (s < p.S) p.P[(long)bh * p.S + s] = pr;
+  }
   __syncthreads();
   float o = 0.f;
   const float* vb = p.v + (long)b * p.S * p.ldv + h * 32 + l31;
-  const int s_end = min(p.S, w * 64 + 64);
-  for (int k = w * 64 + hi; k < s_end; k += 2) o += ps[k] * vb[(long)k * p.ldv];
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s0 = ch * 256 + w * 64, s_end = min(p.S, s0 + 64);
+    for (int k = s0 + hi; k < s_end; k += 2) o += ps[k] * vb[(long)k * p.ldv];
+  }
   o += __shfl_xor(o, 32);
   if (hi == 0) opart[w][l31] = o;
   __syncthreads();
   if (t < 32) p.out[(long)b * p.H * 32 + h * 32 + t] = opart[0][t] + opart[1][t] + opart[2][t] + opart[3][t];
 }
 
+template <int NC>
 __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
   p.drop = stcat_drop_resolve(p.drop);
-  __shared__ float dss[STCAT_Q1_MAXC * 64];
+  __shared__ float dss[NC * 256];
   __shared__ float red[4];
   __shared__ float qpart[2][4][32];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -438,51 +686,64 @@ __global__ void __launch_bounds__(256) attn_q1_bwd_kernel(AttnQ1Params p) {
     float4 u4 = p.q2 ? stcat_ld4(p.q2 + (long)b * p.ldq + h * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     qb[c * 4] = u4.x; qb[c * 4 + 1] = u4.y; qb[c * 4 + 2] = u4.z; qb[c * 4 + 3] = u4.w;
   }
-  const int s = w * 64 + lane;
-  float pr = 0.f, dp = 0.f, dm = 1.f;
-  if (s < p.S) {
-    pr = p.P[(long)bh * p.S + s];
-    const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
-    float dot = 0.f;
-    STCAT_UNROLL
-    for (int d4 = 0; d4 < 8; ++d4) {
-      float4 vv = stcat_ld4(vr + d4 * 4);
-      dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
+  float pr[NC], dp[NC], dm[NC];
+  float dloc = 0.f;
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s = ch * 256 + w * 64 + lane;
+    pr[ch] = 0.f; dp[ch] = 0.f; dm[ch] = 1.f;
+    if (s < p.S) {
+      pr[ch] = p.P[(long)bh * p.S + s];
+      const float* vr = p.v + ((long)b * p.S + s) * p.ldv + h * 32;
+      float dot = 0.f;
+      STCAT_UNROLL
+      for (int d4 = 0; d4 < 8; ++d4) {
+        float4 vv = stcat_ld4(vr + d4 * 4);
+        dot += vv.x * go[d4 * 4] + vv.y * go[d4 * 4 + 1] + vv.z * go[d4 * 4 + 2] + vv.w * go[d4 * 4 + 3];
+      }
+      dm[ch] = stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
+      dp[ch] = dot * dm[ch];  // dP = M' * (dO . V)
     }
-    dm = stcat_drop_mul(p.drop, (unsigned long long)bh * p.S + s);
-    dp = dot * dm;  // dP = M' * (dO . V)
+    dloc += pr[ch] * dp[ch];
   }
-  const float dw = stcat_wave_sum(pr * dp);
+  const float dw = stcat_wave_sum(dloc);
   if (lane == 0) red[w] = dw;
   __syncthreads();
   const float delta = red[0] + red[1] + red[2] + red[3];
-  const float ds = pr * (dp - delta) * p.scale;
-  const float pd = pr * dm;  // dV = P' dO
-  dss[s] = ds;
-  if (s < p.S) {
-    float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
-    float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
-    STCAT_UNROLL
-    for (int d4 = 0; d4 < 8; ++d4) {
-      stcat_st4(gv + d4 * 4, make_float4(pd * go[d4 * 4], pd * go[d4 * 4 + 1], pd * go[d4 * 4 + 2], pd * go[d4 * 4 + 3]));
-      stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2], ds * qa[d4 * 4 + 3]));
-    }
-    if (p.dk2) {
-      float* gk2 = p.dk2 + ((long)b * p.S + s) * HD + h * 32;
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s = ch * 256 + w * 64 + lane;
+    const float ds = pr[ch] * (dp[ch] - delta) * p.scale;
+    const float pd = pr[ch] * dm[ch];  // dV = P' dO
+    dss[s] = ds;
+    if (s < p.S) {
+      float* gv = p.dv + ((long)b * p.S + s) * HD + h * 32;
+      float* gk1 = p.dk1 + ((long)b * p.S + s) * HD + h * 32;
       STCAT_UNROLL
-      for (int d4 = 0; d4 < 8; ++d4)
-        stcat_st4(gk2 + d4 * 4, make_float4(ds * qb[d4 * 4], ds * qb[d4 * 4 + 1], ds * qb[d4 * 4 + 2], ds * qb[d4 * 4 + 3]));
+      for (int d4 = 0; d4 < 8; ++d4) {
+        stcat_st4(gv + d4 * 4, make_float4(pd * go[d4 * 4], pd * go[d4 * 4 + 1], pd * go[d4 * 4 + 2], pd * go[d4 * 4 + 3]));
+        stcat_st4(gk1 + d4 * 4, make_float4(ds * qa[d4 * 4], ds * qa[d4 * 4 + 1], ds * qa[d4 * 4 + 2], ds * qa[d4 * 4 + 3]));
+      }
+      if (p.dk2) {
+        float* gk2 = p.dk2 + ((long)b * p.S + s) * HD + h * 32;
+        STCAT_UNROLL
+        for (int d4 = 0; d4 < 8; ++d4)
+          stcat_st4(gk2 + d4 * 4, make_float4(ds * qb[d4 * 4], ds * qb[d4 * 4 + 1], ds * qb[d4 * 4 + 2], ds * qb[d4 * 4 + 3]));
+      }
     }
   }
   __syncthreads();
   float a1 = 0.f, a2 = 0.f;
   const float* k1b = p.k1 + (long)b * p.S * p.ldk + h * 32 + l31;
   const float* k2b = p.k2 ? p.k2 + (long)b * p.S * p.ldk + h * 32 + l31 : nullptr;
-  const int s_end = min(p.S, w * 64 + 64);
-  for (int k = w * 64 + hi; k < s_end; k += 2) {
-    const float d = dss[k];
-    a1 += d * k1b[(long)k * p.ldk];
-    if (k2b) a2 += d * k2b[(long)k * p.ldk];
+  STCAT_UNROLL
+  for (int ch = 0; ch < NC; ++ch) {
+    const int s0 = ch * 256 + w * 64, s_end = min(p.S, s0 + 64);
+    for (int k = s0 + hi; k < s_end; k += 2) {
+      const float d = dss[k];
+      a1 += d * k1b[(long)k * p.ldk];
+      if (k2b) a2 += d * k2b[(long)k * p.ldk];
+    }
   }
   a1 += __shfl_xor(a1, 32);
   a2 += __shfl_xor(a2, 32);

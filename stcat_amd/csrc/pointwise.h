@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) weight_transpose_multi_kernel(const WtEnt
 
 
 // ---------------------------------------------------------------------------------------------------
-// 2D temporal map head (models/map2d_head.py) — optional op, forward only (the reference never wires it into a loss).
+// 2D temporal map head (models/map2d_head.py) — optional op (the reference never wires it into a loss); forward + backward.
 // Gen2DMap (:9-62) = adaptive pooling of the T frame features to N steps, then 39 cascaded MaxPool1d layers written on
 // sparse diagonals.  In closed form every valid cell (i, j) holds the RANGE MAXIMUM of the pooled sequence over [i, j]
 // (verified equal to the cascade, tests/golden/map2d.npz), so the cascade becomes two small kernels.
@@ -510,6 +510,51 @@ __global__ void __launch_bounds__(256) map2d_cells_kernel(const float* pooled, c
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
     stcat_st4(map + (((long)bb * N + i0) * N + j0) * D + d4 * 4, m);
+  }
+}
+
+// Backward of the two kernels above (TempPredictionHead in train mode returns raw scores for a loss, map2d_head.py:122-124).
+// A cell's gradient goes to the FIRST maximum of its range, which is where the reference's cascade of max-pools routes it
+// (every MaxPool1d backward picks the first maximum of its window; a cascade of them the leftmost of the range).
+__global__ void __launch_bounds__(256) map2d_cells_bwd_kernel(const float* pooled, const int* ci, const int* cj, int ncells,
+                                                             const float* dmap, float* dpooled, int b, int N, int D) {
+  const long total = (long)b * ncells * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D), c = (int)((i / D) % ncells), bb = (int)(i / ((long)D * ncells));
+    const int i0 = ci[c], j0 = cj[c];
+    const float* src = pooled + ((long)bb * N) * D + d;
+    float best = src[(long)i0 * D];
+    int arg = i0;
+    for (int n = i0 + 1; n <= j0; ++n) {
+      const float v = src[(long)n * D];
+      if (v > best) { best = v; arg = n; }
+    }
+    const float g = dmap[(((long)bb * N + i0) * N + j0) * D + d];
+    atomicAdd(&dpooled[((long)bb * N + arg) * D + d], g);
+  }
+}
+// dx (zeroed by the caller) += the gradient of pooled: T > N averages its window, T <= N takes the (first) maximum of it
+__global__ void __launch_bounds__(256) map2d_pool_bwd_kernel(const float* x, const float* dpooled, float* dx, int b, int T,
+                                                            int N, int D) {
+  const long total = (long)b * N * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D), n = (int)((i / D) % N), bb = (int)(i / ((long)D * N));
+    const int s = (n * T) / N, e = ((n + 1) * T + N - 1) / N;
+    const float g = dpooled[i];
+    float* dst = dx + ((long)bb * T) * D + d;
+    if (T > N) {
+      const float gi = g / (float)(e - s);
+      for (int t = s; t < e; ++t) atomicAdd(&dst[(long)t * D], gi);
+    } else {
+      const float* src = x + ((long)bb * T) * D + d;
+      float best = src[(long)s * D];
+      int arg = s;
+      for (int t = s + 1; t < e; ++t) {
+        const float v = src[(long)t * D];
+        if (v > best) { best = v; arg = t; }
+      }
+      atomicAdd(&dst[(long)arg * D], g);
+    }
   }
 }
 

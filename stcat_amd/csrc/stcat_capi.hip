@@ -925,6 +925,13 @@ int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const uns
   AttnParams p = {q, k, v, o, pt, kpm, B, H, S, ldq, ldk, ldv, ldo, scale,
                   stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base)};
   const int nt = cdiv(S, 32);
+  if (nt > 8) {   // 256 < S <= 512 (non-square clips): K / V in dynamic LDS, 8 query tiles per workgroup
+    if (nt > 16) return fail("mha_self_fwd: S=%d exceeds 512 tokens per frame", S);
+    const int lds = nt * 32 * (33 + 32 + 1) * 4;
+    if (int rc = pl_prepare(mha_self_fwd_long_kernel, 160 * 1024)) return rc;
+    STCAT_LAUNCH(mha_self_fwd_long_kernel, dim3(B * H, cdiv(nt, 8)), dim3(512), lds, (hipStream_t)stream, p);
+    return launch_status();
+  }
   STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_fwd_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
   return launch_status();
 }
@@ -946,6 +953,16 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
     STCAT_LAUNCH(attn_dw_corr_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, pt, dw, corr, B, H, S, nt * 32,
                  p.drop);
   }
+  if (nt > 8) {
+    if (nt > 16) return fail("mha_self_bwd: S=%d exceeds 512 tokens per frame", S);
+    const int lds_q = nt * 32 * (33 + 32) * 4, lds_kv = nt * 32 * 64 * 4;
+    if (int rc = pl_prepare(mha_self_bwd_dq_long_kernel, 160 * 1024)) return rc;
+    if (int rc = pl_prepare(mha_self_bwd_dkv_long_kernel, 160 * 1024)) return rc;
+    STCAT_LAUNCH(mha_self_bwd_dq_long_kernel, dim3(B * H, cdiv(nt, 8)), dim3(512), lds_q, (hipStream_t)stream, p);
+    if (int rc = launch_status()) return rc;
+    STCAT_LAUNCH(mha_self_bwd_dkv_long_kernel, dim3(B * H, cdiv(nt, 8)), dim3(512), lds_kv, (hipStream_t)stream, p);
+    return launch_status();
+  }
   STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_bwd_dq_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
   int rc = launch_status();
   if (rc) return rc;
@@ -964,13 +981,17 @@ int stcat_attn_weights_mean(const float* pt, float* w, int B, int H, int S, floa
 int stcat_attn_q1_fwd(const float* q1, const float* q2, const float* k1, const float* k2, const float* v,
                       const unsigned char* kpm, float* out, float* P, int B, int H, int S, int ldq, int ldk,
                       int ldv, float scale, float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream) {
-  if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
+  if (S <= 0 || S > 256 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 256 * STCAT_Q1_MAXC);
   if ((ldq | ldk | ldv) % 4 != 0) return fail("attn_q1: ld %% 4 != 0");
   AttnQ1Params p = {};
   p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.kpm = kpm; p.out = out; p.P = P;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
-  STCAT_LAUNCH(attn_q1_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
+  switch ((S + 255) / 256) {   // 256-key chunks per (frame, head)
+    case 1: STCAT_LAUNCH(attn_q1_fwd_kernel<1>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+    case 2: STCAT_LAUNCH(attn_q1_fwd_kernel<2>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+    default: STCAT_LAUNCH(attn_q1_fwd_kernel<STCAT_Q1_MAXC>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+  }
   return launch_status();
 }
 
@@ -978,13 +999,17 @@ int stcat_attn_q1_bwd(const float* q1, const float* q2, const float* k1, const f
                       const float* P, const float* dout, float* dq1, float* dq2, float* dk1, float* dk2, float* dv,
                       int B, int H, int S, int ldq, int ldk, int ldv, float scale, float drop_p, long drop_seed,
                       long drop_offset, const long* drop_base, void* stream) {
-  if (S <= 0 || S > 64 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 64 * STCAT_Q1_MAXC);
+  if (S <= 0 || S > 256 * STCAT_Q1_MAXC) return fail("attn_q1: S=%d out of range (1..%d)", S, 256 * STCAT_Q1_MAXC);
   AttnQ1Params p = {};
   p.q1 = q1; p.q2 = q2; p.k1 = k1; p.k2 = k2; p.v = v; p.P = const_cast<float*>(P); p.dout = dout;
   p.dq1 = dq1; p.dq2 = dq2; p.dk1 = dk1; p.dk2 = dk2; p.dv = dv;
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
-  STCAT_LAUNCH(attn_q1_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p);
+  switch ((S + 255) / 256) {
+    case 1: STCAT_LAUNCH(attn_q1_bwd_kernel<1>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+    case 2: STCAT_LAUNCH(attn_q1_bwd_kernel<2>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+    default: STCAT_LAUNCH(attn_q1_bwd_kernel<STCAT_Q1_MAXC>, dim3(B * H), dim3(256), 0, (hipStream_t)stream, p); break;
+  }
   return launch_status();
 }
 
@@ -1223,7 +1248,7 @@ int stcat_mha_bs_bwd(const float* q, const float* k, const float* v, const unsig
   return launch_status();
 }
 
-// ---- 2D temporal map head (models/map2d_head.py), optional op, forward only -------------------------------------
+// ---- 2D temporal map head (models/map2d_head.py), optional op -------------------------------------
 int stcat_map2d_pool(const float* x, float* pooled, int b, int T, int N, int D, void* stream) {
   if (b <= 0 || T <= 0 || N <= 0 || D <= 0) return fail("map2d_pool: bad shape");
   STCAT_LAUNCH(map2d_pool_kernel, dim3(grid_for((long)b * N * D, 256)), dim3(256), 0, (hipStream_t)stream, x, pooled, b, T,
@@ -1236,6 +1261,21 @@ int stcat_map2d_cells(const float* pooled, const int* cell_i, const int* cell_j,
   if (D % 4 != 0 || ncells <= 0) return fail("map2d_cells: D %% 4 != 0 or no cells");
   STCAT_LAUNCH(map2d_cells_kernel, dim3(grid_for((long)b * ncells * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                pooled, cell_i, cell_j, ncells, map, b, N, D);
+  return launch_status();
+}
+
+int stcat_map2d_cells_bwd(const float* pooled, const int* cell_i, const int* cell_j, int ncells, const float* dmap,
+                          float* dpooled, int b, int N, int D, void* stream) {
+  if (ncells <= 0 || b <= 0 || N <= 0 || D <= 0) return fail("map2d_cells_bwd: bad shape");
+  STCAT_LAUNCH(map2d_cells_bwd_kernel, dim3(grid_for((long)b * ncells * D, 256)), dim3(256), 0, (hipStream_t)stream, pooled,
+               cell_i, cell_j, ncells, dmap, dpooled, b, N, D);
+  return launch_status();
+}
+
+int stcat_map2d_pool_bwd(const float* x, const float* dpooled, float* dx, int b, int T, int N, int D, void* stream) {
+  if (b <= 0 || T <= 0 || N <= 0 || D <= 0) return fail("map2d_pool_bwd: bad shape");
+  STCAT_LAUNCH(map2d_pool_bwd_kernel, dim3(grid_for((long)b * N * D, 256)), dim3(256), 0, (hipStream_t)stream, x, dpooled, dx,
+               b, T, N, D);
   return launch_status();
 }
 
@@ -1291,6 +1331,8 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_attn_q1_bwd),
     STCAT_PLAN_FN(stcat_map2d_pool),
     STCAT_PLAN_FN(stcat_map2d_cells),
+    STCAT_PLAN_FN(stcat_map2d_cells_bwd),
+    STCAT_PLAN_FN(stcat_map2d_pool_bwd),
     STCAT_PLAN_FN(stcat_rowscale),
     STCAT_PLAN_FN(stcat_grad_sqnorm),
     STCAT_PLAN_FN(stcat_grad_clip_scale),
@@ -1369,6 +1411,13 @@ int stcat_plan_add_memset(void* h, void* ptr, unsigned long long bytes, int slot
   pl->words.push_back((uint64_t)bytes);
   if (at_front) pl->ops.insert(pl->ops.begin(), op); else pl->ops.push_back(op);
   return (int)op.arg0;
+}
+
+int stcat_plan_set_word(void* h, int word, unsigned long long value) {
+  stcat_plan::Plan* pl = plan_of(h);
+  if (!pl || word < 0 || (size_t)word >= pl->words.size()) return fail("plan_set_word: bad word index");
+  pl->words[word] = (uint64_t)value;
+  return 0;
 }
 
 int stcat_plan_add_yield(void* h, int tag) {

@@ -784,7 +784,10 @@ class MhaSelfFn(Function):
         # The fp32-MFMA kernels remain for the exact-fp32 mode and for the one caller that consumes the head-mean
         # weights (the time decoder's self-attention, T queries).
         # (mode bf16x6p is fp32-class end to end: its attention runs on the fp32 matrix pipe as well)
-        ctx.bs = (not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p")
+        # rows longer than 256 tokens (non-square clips) train through the fp32 long-row kernels in every mode: the
+        # bf16-pipe backward keeps a whole row's tiles in LDS and is built for S <= 256
+        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p")
+                  and (S <= 256 or not any(ctx.needs_input_grad[:3])))
         if ctx.bs:
             keep = any(ctx.needs_input_grad[:3])
             lse = _empty(v, B, H, S) if keep else None

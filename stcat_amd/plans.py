@@ -8,8 +8,8 @@ input SHAPES only, so each is recorded once and replayed:
 * first call of a (node, input signature): plain eager Python (fills the per-module caches);
 * second call: the same Python path runs under a `Recorder` — every `_lib.call` is also appended to a C++ plan, every
   tensor it allocates comes from the plan's private `torch.cuda.MemPool` (kept for the life of the plan, so the baked
-  addresses stay valid), zero-initialised accumulators come from plan-owned chunks that ONE memset per chunk clears at
-  the top of a replay;
+  addresses stay valid), zero-initialised accumulators come from plan-owned chunks, each cleared by ONE memset op at
+  the point of the sequence where the chunk was opened;
 * from the third call on: `stcat_plan_run` — pointers into the tensors the caller passes in per step (inputs,
   parameters, upstream gradients: the "externals") are patched by a relocation list, everything else is static.
 
@@ -35,6 +35,7 @@ from . import _lib as L
 
 ENABLED = bool(os.environ.get("STCAT_PLANS"))
 STRICT = bool(os.environ.get("STCAT_PLAN_STRICT"))   # raise when a recorded region runs a kernel that is not ours
+KEEPALL = bool(os.environ.get("STCAT_PLAN_KEEPALL"))  # debug: no block of the plan's pool is reused inside a recording
 WARMUP_CALLS = 1
 STATIC_EPOCH = 0     # bumped whenever a cached device object the plans point at is rebuilt (FrozenBN fold, weight planes)
 MAX_PLANS_PER_NODE = 8
@@ -129,7 +130,7 @@ class Recorder:
         self.keep: List[torch.Tensor] = []
         self.foreign: List[str] = []
         self.allow_foreign = False
-        self.zero_chunks = []                   # [buffer, used elements]
+        self.zero_chunks = {}                   # stream slot -> [[buffer, used elements, memset word], ...]
         self.ext = externals
         self._fn = {}
         from . import ops
@@ -200,23 +201,33 @@ class Recorder:
         self.effects.append(fn)
 
     def zeros(self, shape) -> torch.Tensor:
+        """a zeroed fp32 buffer from the plan's accumulation chunks.  A chunk is cleared by ONE memset op that sits at the
+        point of the sequence where the chunk was opened, on the stream that opened it (its block may have served an
+        earlier temporary of the same recording: clearing it at the top of the plan would be undone by that temporary's
+        kernels), and chunks are per stream (the weight-gradient stream's accumulators are cleared on that stream)."""
         n = 1
         for d in shape:
             n *= int(d)
-        if self.zero_chunks:
-            buf, used = self.zero_chunks[-1]
-            start = (used + 63) & ~63
-            if start + n <= buf.numel():
-                self.zero_chunks[-1][1] = start + n
-                return buf[start:start + n].view(*shape)
-        size = max(n, min(1 << 24, (1 << 20) << len(self.zero_chunks)))
+        stream = torch.cuda.current_stream(self.dev) if self.cuda else None
+        slot = self._slot(stream.cuda_stream, stream) if stream is not None else 0
+        chunks = self.zero_chunks.setdefault(slot, [])
+        if chunks:
+            ch = chunks[-1]
+            start = (ch[1] + 63) & ~63
+            if start + n <= ch[0].numel():
+                ch[1] = start + n
+                return ch[0][start:start + n].view(*shape)
+        size = max(n, min(1 << 24, (1 << 20) << len(chunks)))
         self.allow_foreign = True
         try:
             buf = torch.zeros(size, device=self.dev, dtype=torch.float32)
         finally:
             self.allow_foreign = False
         self.keep.append(buf)
-        self.zero_chunks.append([buf, n])
+        w = self.lib.stcat_plan_add_memset(self.h, buf.data_ptr(), size * 4, slot, 0)
+        if w < 0:
+            raise L.StcatHipError(self.lib.stcat_last_error().decode())
+        chunks.append([buf, n, w])
         return buf[:n].view(*shape)
 
     # ---- finish ---------------------------------------------------------------------------------------------------
@@ -243,9 +254,10 @@ class Recorder:
                     if p - lo > (1 << 36):
                         break
                     i -= 1
-        for buf, used in self.zero_chunks:
-            if lib.stcat_plan_add_memset(self.h, buf.data_ptr(), used * 4, 0, 1) < 0:
-                raise L.StcatHipError(lib.stcat_last_error().decode())
+        for chunks in self.zero_chunks.values():
+            for buf, used, w in chunks:        # the memset clears what was handed out, not the whole chunk
+                if lib.stcat_plan_set_word(self.h, w + 1, used * 4) != 0:
+                    raise L.StcatHipError(lib.stcat_last_error().decode())
         from . import ops
         return Plan(self, ops._dropout_stream.offset, n_reloc)
 
@@ -387,7 +399,7 @@ def _record(dev, ext, pool, body):
     """run body() with every launch mirrored into a new plan; returns (result, Plan)"""
     rec = Recorder(dev, ext)
     cuda = dev.type == "cuda"
-    watch = _Watch(rec, keepalive=not cuda) if (STRICT or not cuda) else None
+    watch = _Watch(rec, keepalive=(not cuda) or KEEPALL) if (STRICT or KEEPALL or not cuda) else None
     prev = L.RECORDER
     L.RECORDER = rec
     try:

@@ -449,6 +449,54 @@ def map2d_vectors():
             g["map2d/head/x"] = xh.numpy()
             g["map2d/head/scores"] = head(xh).numpy()     # eval: sigmoid(scores) * mask  [layers, b, N, N]
         g["map2d/head/keys"] = np.array(list(head.state_dict().keys()))
+
+        def fill(hd, prefix):
+            with torch.no_grad():
+                for k, v in hd.state_dict().items():
+                    v.copy_(torch.from_numpy(synth.synth_value(prefix + k, tuple(v.shape))))
+
+        def train_vectors(hd, x, tag, full_grads=True):
+            """train mode (map2d_head.py:122-124: raw scores) + the gradients of sum(scores * G) — what a loss on the map
+            would send back (round 3: the head's backward)"""
+            hd.train()
+            xr = x.clone().requires_grad_(True)
+            sc = hd(xr)
+            G = torch.from_numpy(synth.hash_normal(f"op/map2d/{tag}/G", sc.numel()).reshape(tuple(sc.shape)))
+            g[f"map2d/{tag}/train_scores"] = sc.detach().numpy().copy()
+            g[f"map2d/{tag}/G"] = G.numpy()
+            (sc * G).sum().backward()
+            g[f"map2d/{tag}/dx"] = xr.grad.numpy().copy()
+            for k, prm in hd.named_parameters():
+                if full_grads:
+                    g[f"map2d/{tag}/grad/{k}"] = prm.grad.numpy().copy()
+                else:
+                    g[f"map2d/{tag}/gradnorm/{k}"] = np.array(float(prm.grad.double().norm()))
+
+        # conv variant, train mode + backward (same weights / input as the eval vector above)
+        train_vectors(head, xh, "head")
+        # 'attn' variant (:130-205) at the model's width (HIDDEN 256, 8 heads: head dimension 32, LayerNorm(256)), small map,
+        # dropout 0 so train mode is deterministic
+        cfg_a = NS(MODEL=NS(TEMPFORMER=NS(**dict(MAP2D_CFG, TEMP_HEAD="attn", HIDDEN=256, HEADS=8, DROPOUT=0.0))))
+        head_a = m.TempPredictionHead(cfg_a).eval()
+        fill(head_a, "map2d_attn_head.")
+        g["map2d/attn/keys"] = np.array(list(head_a.state_dict().keys()))
+        xa = torch.from_numpy(synth.hash_normal("op/map2d/xa", 2 * 1 * 20 * 256).reshape(2, 1, 20, 256))
+        g["map2d/attn/x"] = xa.numpy()
+        with torch.no_grad():
+            g["map2d/attn/scores"] = head_a(xa.clone()).numpy()
+            head_a.train()     # raw scores (:122-124).  No gradient vector: the reference's `map2d[i] = encoder(map2d[i])`
+            #                    (:113-115) overwrites a tensor its own backward needs — autograd refuses to differentiate it
+            g["map2d/attn/train_scores"] = head_a(xa.clone()).numpy()
+        # the reference-sized head: 128 x 128 map, 256 channels, four 9 x 9 convolutions (VERDICT r02 #8)
+        cfg_f = NS(MODEL=NS(TEMPFORMER=NS(**dict(MAP2D_CFG, MAX_MAP_SIZE=128, POOLING_COUNTS=[15, 8, 8, 8], HIDDEN=256,
+                                                  KERNAL_SIZE=9, CONV_LAYERS=4))))
+        head_f = m.TempPredictionHead(cfg_f).eval()
+        fill(head_f, "map2d_full_head.")
+        xf = torch.from_numpy(synth.hash_normal("op/map2d/xf", 2 * 64 * 256).reshape(2, 1, 64, 256))  # (one map would be squeezed away, :119)
+        g["map2d/full/x"] = xf.numpy()
+        with torch.no_grad():
+            g["map2d/full/scores"] = head_f(xf.clone()).numpy()
+        train_vectors(head_f, xf, "full", full_grads=False)
     finally:
         torch.Tensor.to = orig_to
     return g

@@ -26,33 +26,49 @@ THROUGHPUT_MMA = "bf16x3p"  # bench.py's `throughput_mode` (two planes: 16 signi
 GRAD_ABS_FLOOR = 2e-6
 
 
-def _run_hip(dev, T, res, L, with_backward=True, mma="f32"):
+def _clip_of(T, res, pad=None):
+    """frames [T,3,H,W] + padding mask [T,H,W]; res = side of a square clip or (H, W).  pad="ragged": frames of
+    different extents inside one padded tensor, as NestedTensor.from_tensor_list builds them (zeros + mask = True):
+    the last frame loses its right quarter, frame 1 its bottom eighth, frame 2 both."""
+    H, W = (res, res) if isinstance(res, int) else res
+    frames = synth.synth_frames(T, max(H, W))[:, :, :H, :W].contiguous()
+    mask = torch.zeros(T, H, W, dtype=torch.bool)
+    if pad == "ragged":
+        mask[T - 1, :, W - W // 4:] = True
+        mask[1 % T, H - H // 8:, :] = True
+        mask[2 % T, H - H // 8:, :] = True
+        mask[2 % T, :, W - W // 4:] = True
+        frames = frames.masked_fill(mask[:, None], 0.0)
+    return frames, mask, H, W
+
+
+def _run_hip(dev, T, res, L, with_backward=True, mma="f32", pad=None):
     from stcat_amd import _lib
     _lib.set_mma_mode(mma)
     try:
-        return _run_hip_impl(dev, T, res, L, with_backward)
+        return _run_hip_impl(dev, T, res, L, with_backward, pad)
     finally:
         _lib.set_mma_mode("f32")
 
 
-def _run_hip_impl(dev, T, res, L, with_backward):
+def _run_hip_impl(dev, T, res, L, with_backward, pad=None):
     text = synth.synth_text(L)
     model, criterion, wd = build_model(None, SyntheticText(text))
     model.eval()
     synth.fill_module_(model)
     model.to(dev)
-    frames = synth.synth_frames(T, res).to(dev)
-    mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+    frames, mask, H, W = _clip_of(T, res, pad)
+    frames, mask = frames.to(dev), mask.to(dev)
     out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
     keep = {k: v.detach().cpu().clone() for k, v in out.items() if torch.is_tensor(v)}
     keep["aux"] = [{k: v.detach().cpu().clone() for k, v in a.items()} for a in out["aux_outputs"]]
-    sizes = torch.tensor([[float(res), float(res)]], device=dev).repeat(T, 1)
+    sizes = torch.tensor([[float(H), float(W)]], device=dev).repeat(T, 1)
     boxes, sted = build_postprocessors()(out, sizes, [list(range(100, 100 + T))], [T])
     keep["post_boxes"], keep["post_sted"] = boxes.cpu(), sted
     losses = grads = None
     if with_backward or with_backward == "loss":
         act, tb = synth.synth_targets(T)
-        targets = [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}]
+        targets = [{"actioness": act.to(dev), "boxs": BoxList(tb, (W, H)).to(dev)}]
         losses = criterion(out, targets, [T])
         total = sum(losses[k] * wd[k] for k in losses)
         if with_backward is True:
@@ -63,25 +79,25 @@ def _run_hip_impl(dev, T, res, L, with_backward):
     return keep, losses, grads
 
 
-def _run_oracle(T, res, L, with_backward=True, dtype=torch.float32):
+def _run_oracle(T, res, L, with_backward=True, dtype=torch.float32, pad=None):
     """dtype=float64 gives the 'exact arithmetic' yardstick used to calibrate gradient tolerances."""
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
     try:
-        return _run_oracle_impl(T, res, L, with_backward, dtype)
+        return _run_oracle_impl(T, res, L, with_backward, dtype, pad)
     finally:
         torch.set_default_dtype(prev)
 
 
-def _run_oracle_impl(T, res, L, with_backward, dtype):
+def _run_oracle_impl(T, res, L, with_backward, dtype, pad=None):
     sd = {k: v.to(dtype) for k, v in synth.synth_state_dict().items()}
     for v in sd.values():
         v.requires_grad_(True)
-    frames = synth.synth_frames(T, res).to(dtype)
-    mask = torch.zeros(T, res, res, dtype=torch.bool)
+    frames, mask, H, W = _clip_of(T, res, pad)
+    frames = frames.to(dtype)
     (tm, tmem, _), tcls = synth.synth_text(L)
     out = O.stcat_forward(sd, frames, mask, ((tm, tmem.to(dtype), None), tcls.to(dtype)))
-    sizes = torch.tensor([[float(res), float(res)]]).repeat(T, 1)
+    sizes = torch.tensor([[float(H), float(W)]]).repeat(T, 1)
     boxes, sted, _ = O.post_process(out["pred_sted"].detach(), out["pred_boxes"].detach(), sizes,
                                     list(range(100, 100 + T)), T)
     losses = grads = None
@@ -442,6 +458,65 @@ def test_gpu_c3_full_size_forward_backward_throughput_mode():
     hip = _run_hip(dev, T, res, L, mma=THROUGHPUT_MMA)
     ref, g64 = _c3_oracle()
     _compare(hip, ref, g64=g64, grad_caps=GRAD_CAPS_16BIT)
+
+
+# ---- non-square and padded clips ---------------------------------------------------------------------
+# The reference's transforms (datasets/build.py:20-44: short side 448, max_size 720) turn a 16:9 video into 405 x 720
+# frames: a 13 x 23 layer4 map, 13*23 + L + 1 = 310 tokens per frame in the encoder, 309 keys per frame in the decoders'
+# time-aligned cross-attention — more than the 256 the round-2 kernels were built for.  Padding masks
+# (modal_encoder.py:46, query_decoder.py:111) are exercised at model level here, not only per op.
+def test_emu_nonsquare_padded_clip_forward_backward():
+    """96 x 160 frames (3 x 5 map) with a ragged padding mask, through the host emulator: H != W everywhere, key-padding
+    in every attention of the assembled model, forward + loss + backward against the oracle."""
+    dev = use_emu()
+    g64 = _run_oracle(3, (96, 160), 3, dtype=torch.float64, pad="ragged")[4]
+    _compare(_run_hip(dev, 3, (96, 160), 3, pad="ragged"), _run_oracle(3, (96, 160), 3, pad="ragged"), g64=g64)
+
+
+@pytest.mark.gpu
+def test_gpu_nonsquare_405x720_padded_clip_forward_backward():
+    """T=8 frames of 405 x 720 (what the reference's resize makes of a 16:9 video), L=10, ragged padding on three frames:
+    310 encoder tokens / 309 decoder keys per frame -> the long-row self-attention kernels and the two-chunk one-query
+    cross-attention, odd H (405 -> 203 -> 102 -> 51 -> 26 -> 13) and W % 32 != 0 in every conv.  Forward + loss +
+    backward in the bench arithmetic vs the CPU oracle: outputs 1e-3 absolute, span bit-exact, calibrated gradients."""
+    dev = use_hip()
+    T, res, L = 8, (405, 720), 10
+    g64 = _run_oracle(T, res, L, dtype=torch.float64, pad="ragged")[4]
+    # grad_slack 4: a padded margin is thousands of pixels with IDENTICAL activations (bias only), so a pre-activation
+    # that rounds to either side of zero there flips the ReLU of the whole margin at once — the conv gradients of a few
+    # layer3 blocks then sit at 0.4-1.3e-2 from exact where the un-padded clip (next test, slack 1) and the padded
+    # square clip pass the calibrated bound.  Outputs, span and the 30 loss terms are held to the usual bars.
+    _compare(_run_hip(dev, T, res, L, mma=BENCH_MMA, pad="ragged"), _run_oracle(T, res, L, pad="ragged"), g64=g64,
+             grad_slack=4.0)
+
+
+@pytest.mark.gpu
+def test_gpu_nonsquare_405x720_clip_forward_backward():
+    """the same 405 x 720 clip without padding (mask all False, what the reference's loader produces with one video per
+    rank): isolates the non-square geometry from the padding"""
+    dev = use_hip()
+    T, res, L = 8, (405, 720), 10
+    g64 = _run_oracle(T, res, L, dtype=torch.float64)[4]
+    _compare(_run_hip(dev, T, res, L, mma=BENCH_MMA), _run_oracle(T, res, L), g64=g64)
+
+
+@pytest.mark.gpu
+def test_gpu_square_clip_with_padding_mask():
+    """C1-sized square clip whose mask is NOT all-zero (three partially padded frames): fwd + loss + bwd, bench arithmetic"""
+    dev = use_hip()
+    g64 = _run_oracle(8, 224, 10, dtype=torch.float64, pad="ragged")[4]
+    _compare(_run_hip(dev, 8, 224, 10, mma=BENCH_MMA, pad="ragged"), _run_oracle(8, 224, 10, pad="ragged"), g64=g64)
+
+
+@pytest.mark.gpu
+def test_gpu_nonsquare_clip_throughput_mode():
+    """the same 405 x 720 clip in the 16-bit throughput mode: rows longer than 256 tokens train through the fp32 long-row
+    attention kernels there too (ops.MhaSelfFn); forward + loss + backward, family caps on the gradients"""
+    dev = use_hip()
+    T, res, L = 4, (405, 720), 10
+    g64 = _run_oracle(T, res, L, dtype=torch.float64, pad="ragged")[4]
+    _compare(_run_hip(dev, T, res, L, mma=THROUGHPUT_MMA, pad="ragged"), _run_oracle(T, res, L, pad="ragged"), g64=g64,
+             grad_caps={k: min(4 * v, 5e-2) for k, v in GRAD_CAPS_16BIT.items()})  # (T = 4: few samples per gradient)
 
 
 @pytest.mark.gpu

@@ -409,7 +409,15 @@ def _mha_self(dev, big):
     _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)
     _mha_case(dev, 1, 8, 2, need_w=True, packed=True, masked=False)
     _mha_case(dev, 1, 65, 1, need_w=True, packed=False, masked=True)
+    # more than 256 tokens per frame (non-square clips: 405 x 720 -> 13 x 23 + text + [CLS] = 310): the long-row kernels
+    # (K / V in dynamic LDS, two-pass softmax forward), forward + backward, masked, with and without the weights
+    _mha_case(dev, 1, 310, 1, need_w=False, packed=True, masked=True)
+    _mha_dropout_case(dev, 1, 270, 1, need_w=False)
     if big:
+        _mha_case(dev, 8, 310, 8, need_w=False, packed=True, masked=True)
+        _mha_case(dev, 2, 340, 8, need_w=True, packed=False, masked=True)
+        _mha_case(dev, 2, 512, 8, need_w=False, packed=True, masked=False)
+        _mha_case(dev, 2, 257, 8, need_w=False, packed=True, masked=True)
         _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)
         _mha_case(dev, 3, 237, 8, need_w=False, packed=True, masked=True)
         _mha_case(dev, 1, 64, 8, need_w=True, packed=True, masked=False)
@@ -449,7 +457,11 @@ def _q1_case(dev, B, S, H, two):
 def _attn_q1(dev, big):
     _q1_case(dev, 3, 11, 2, True)
     _q1_case(dev, 5, 70, 1, False)
+    _q1_case(dev, 2, 309, 1, True)      # two 256-key chunks per (frame, head): non-square clips
     if big:
+        _q1_case(dev, 8, 309, 8, True)
+        _q1_case(dev, 8, 339, 8, False)
+        _q1_case(dev, 3, 700, 8, True)  # three chunks (the four-chunk instantiation)
         _q1_case(dev, 64, 206, 8, True)
         _q1_case(dev, 64, 206, 8, False)
         _q1_case(dev, 7, 256, 8, True)
@@ -590,6 +602,8 @@ def _mha_bs(dev, big):
         with torch.no_grad():
             o, _ = ops.mha_self_packed(qk.to(dev), v.to(dev), kpm.to(dev), 32 ** -0.5)
         close(o, o_ref, TOL, "S = 310 forward")
+        # ... and with gradients: rows longer than 256 tokens take the fp32 long-row kernels in every mode
+        _mha_case(dev, 1, 310, 1, need_w=False, packed=True, masked=True)
         if big:
             _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)  # the C3 spatial layer
             _mha_dropout_case(dev, 4, 207, 8, need_w=False, pdrop=0.1)

@@ -80,7 +80,9 @@ def _same(a, b, what, tol):
 
 def _rel_l2(a, b, what, tol):
     assert a.shape == b.shape, what
-    err = (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-12)
+    # absolute floor of 2e-6 per element: key-side attention biases (and layer 0's query-content bias, whose input is the
+    # zero state) have structurally zero gradients — what is left there is rounding noise
+    err = (a.double() - b.double()).norm().item() / (b.double().norm().item() + 2e-6 * b.numel() ** 0.5 / tol)
     assert err <= tol, f"{what}: rel-L2 {err:.3e}"
 
 
