@@ -90,7 +90,7 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
             dw = ops._zeros(g, N, K)
         if db is None and want_db:
             db = ops._zeros(g, N)
-        L.call("stcat_linear_wgrad", g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, x2.stride(0), st)
+        _wgrad(g, x2, dw, db, M, N, K)
     else:
         dx_ = torch.empty(M, K, device=g.device, dtype=torch.float32) if need_dx else None
         dw_ = torch.empty(N, K, device=g.device, dtype=torch.float32)
@@ -101,6 +101,68 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
         dw = dw_ if dw is None else ops.ew(L.EW_ADD, dw, dw_, out=dw)
         db = db_ if db is None else (ops.ew(L.EW_ADD, db, db_, out=db) if db_ is not None else db)
     return dx, dw, db, g
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weight gradients leave the critical path
+# ------------------------------------------------------------------------------------------------------------------
+# A layer's backward is a dependent chain (data gradient -> LayerNorm backward -> attention backward -> ...) of small
+# launches; its weight / bias gradients feed nothing but the optimizer.  Inside a `wgrad_batch` they are collected and
+# issued together on the weight-gradient stream (ops.WgradStream, shared with the backbone) when the layer's chain has
+# been queued: the chain no longer waits behind ~270 weight-gradient launches per step (5.4 ms of kernel time at C3,
+# profiles/r03_timeline.log), which run on CUs the chain leaves idle.  The outermost batch joins the streams, so a node's
+# backward returns with every gradient ordered on its own stream, as autograd expects.
+_BATCH = []          # stack of pending launch lists (innermost last)
+_DIRTY = [False]     # the side stream holds launches the current stream has not waited for yet
+
+
+DEFER_WGRADS = not os.environ.get("STCAT_NO_WGRAD_DEFER")
+
+
+def _wgrad(g, x2, dw, db, M, N, K):
+    args = (g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, x2.stride(0))
+    if _BATCH and DEFER_WGRADS:
+        _BATCH[-1].append((args, g, x2))
+    else:
+        L.call("stcat_linear_wgrad", *args, L.stream_of(g))
+
+
+def wgrad_flush(like: torch.Tensor) -> None:
+    """issue what the innermost batch has collected so far (end of a decoder layer inside its node's batch)"""
+    if not _BATCH or not _BATCH[-1]:
+        return
+    pending = _BATCH[-1]
+    _BATCH[-1] = []
+    wg = ops.WgradStream(like)
+    with wg:
+        st = L.stream_of(like)
+        for args, _, _ in pending:
+            L.call("stcat_linear_wgrad", *args, st)
+    for _, g, x2 in pending:
+        wg.keep(g, x2)
+    _DIRTY[0] = True
+
+
+class wgrad_batch:
+    """`with wgrad_batch(like): <a layer's backward>`; batches nest (a node's backward around its layers)"""
+
+    def __init__(self, like: torch.Tensor):
+        self.like = like
+
+    def __enter__(self):
+        _BATCH.append([])
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            _BATCH.pop()
+            return False
+        wgrad_flush(self.like)
+        _BATCH.pop()
+        if not _BATCH and _DIRTY[0]:
+            ops.WgradStream(self.like).join()
+            _DIRTY[0] = False
+        return False
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -192,6 +254,11 @@ class EncoderLayerFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with wgrad_batch(dy):
+            return EncoderLayerFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         (c_att, st1, st2, x_qk, x_v, D, shp, pos_shape) = ctx.st
         W_in = ctx.W_in
         need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -283,6 +350,11 @@ class TimeDecoderFn(Function):
 
     @staticmethod
     def backward(ctx, d_hs, d_ws):
+        with wgrad_batch(d_hs):
+            return TimeDecoderFn._backward(ctx, d_hs, d_ws)
+
+    @staticmethod
+    def _backward(ctx, d_hs, d_ws):
         T, D, nl = ctx.dims
         prm = ctx.prm
         x_mem, x_mp, mshape = ctx.mem
@@ -323,6 +395,7 @@ class TimeDecoderFn(Function):
             d_qpt = d_qkin if d_qpt is None else _add(d_qpt, d_qkin)
             d_next = None if first else _add(d_t, d_qkin)
             d_layers[i] = (dW_in, dB_in, dWo, dbo, dg1, dbe1, dW_c, dB_c, dWo2, dbo2, dg3, dbe3, dW1, db1, dW2, db2, dg4, dbe4)
+            wgrad_flush(like)
         if need_mem:
             d_mem = _add(d_mem, d_mp).view(mshape)
         d_qp = _add(d_qpos, d_qpt) if need_qpos else None
@@ -451,6 +524,11 @@ class BoxDecoderFn(Function):
 
     @staticmethod
     def backward(ctx, d_hs, d_refs, d_coord):
+        with wgrad_batch(d_hs):
+            return BoxDecoderFn._backward(ctx, d_hs, d_refs, d_coord)
+
+    @staticmethod
+    def _backward(ctx, d_hs, d_refs, d_coord):
         T, D, nl = ctx.dims
         prm, refs = ctx.prm, ctx.refs
         x_mem, x_pos, mshape = ctx.mem
@@ -539,6 +617,7 @@ class BoxDecoderFn(Function):
                 if d_refs is not None:
                     d_anchor = _add(d_anchor, d_refs[0])
             d_next = d_x
+            wgrad_flush(like)
             d_layers[i] = (dWqc, dbqc, dWqp, dbqp, dWqt, dbqt, dWkc, dbkc, dWkp, dbkp, dWkt, dbkt, dWv, dbv, dW_in, dB_in,
                            dWo, dbo, dg1, dbe1, dWcq, dbcq, dWcqp, dbcqp, dWqs, dbqs, dWo2, dbo2, dg3, dbe3, dW1, db1,
                            dW2, db2, dg4, dbe4, dWmk, dbmk, dWmp, dbmp, dWmv, dbmv)
@@ -624,6 +703,12 @@ class EncoderFn(Function):
 
     @staticmethod
     def backward(ctx, d_memory, d_frames, d_video):
+        like = d_memory if d_memory is not None else (d_frames if d_frames is not None else d_video)
+        with wgrad_batch(like):
+            return EncoderFn._backward(ctx, d_memory, d_frames, d_video)
+
+    @staticmethod
+    def _backward(ctx, d_memory, d_frames, d_video):
         n, HW, Lt, d, nl = ctx.dims
         S1 = 1 + HW + Lt
         like = d_memory if d_memory is not None else (d_frames if d_frames is not None else d_video)
@@ -640,7 +725,7 @@ class EncoderFn(Function):
             d_seq2 = ops._empty(like, 1, n + 1, d)
             ops.ew(L.EW_COPY, d_video, out=d_seq2[0, 0:1])
             ops.ew2d(L.EW_COPY, _cols(d_x, 0, 1), out=d_seq2[0, 1:])
-            r = EncoderLayerFn.backward(c_t, d_seq2)
+            r = EncoderLayerFn.backward(c_t, d_seq2)          # (its own wgrad_batch: flushed per layer, joined at the end)
             grads[2 * i + 1] = r[5:]
             d_seq = r[0]
             d_video = d_seq[0, 0:1]

@@ -180,9 +180,12 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
 // forward / data gradient:  C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (tap, c), c fastest
 // 8 waves as WM x WN, wave tile (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32 x 32.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool F32 = false, int NP = 2>
-__global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
-  static_assert(WM * WN == 8, "8 waves");
+template <int BM, int BN, int WM, int WN, bool F32 = false, int NP = 2, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
+  // NW = 8: one workgroup per CU (two waves per SIMD).  NW = 4 (128 x 64 tile, three planes: 74 KB of LDS): TWO workgroups
+  // per CU with the same two waves per SIMD — their phases drift apart, so one's epilogue / first loads (HBM) run under
+  // the other's MFMAs: the form for the K <= 512 1x1 convolutions, whose epilogue traffic is as long as their K loop
+  static_assert(WM * WN == NW, "NW waves");
   static_assert(!(F32 && NP != 2), "the exact-fp32 form keeps the two-plane LDS layout");
   constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NPL = F32 ? 1 : NP;                              // planes actually staged
@@ -190,10 +193,10 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   constexpr int STAGE = NP * (PLANE_A + PLANE_B);                // A planes, then B planes
   static_assert(2 * STAGE <= 160 * 1024, "two stages fit the CU's LDS");
   constexpr int QA = BM / 16, QB = BN / 16;                      // 1-KiB DMA pieces (16 rows) per plane
-  constexpr int RQA = (QA + 7) / 8, RQB = (QB + 7) / 8;          // pieces per wave
+  constexpr int RQA = (QA + NW - 1) / NW, RQB = (QB + NW - 1) / NW;  // pieces per wave
   constexpr int LDE = TN * 32 + 4;                               // epilogue block: 32 rows x (TN*32) fp32, padded
   constexpr int EPI_WAVE = 32 * LDE * 4;
-  static_assert(8 * EPI_WAVE <= 2 * STAGE, "epilogue blocks fit the operand stages");
+  static_assert(NW * EPI_WAVE <= 2 * STAGE, "epilogue blocks fit the operand stages");
   STCAT_DYN_SHARED(char, smem);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
   const int wq = STCAT_READFIRSTLANE(wave);
@@ -214,13 +217,13 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   const int nkh = kh0 < g.KH ? (g.KH - kh0 + kstep - 1) / kstep : 0, nkw = kw0 < g.KW ? (g.KW - kw0 + kstep - 1) / kstep : 0;
   const int nk = p.par ? nkh * nkw * (g.C / BK) : p.K / BK;
 
-  // ---- DMA bookkeeping: piece q = wave + 8 i covers rows 16 q .. 16 q + 15 of a plane; lane -> row 16 q + (lane >> 2),
+  // ---- DMA bookkeeping: piece q = wave + NW i covers rows 16 q .. 16 q + 15 of a plane; lane -> row 16 q + (lane >> 2),
   // LDS chunk (lane & 3) which holds SOURCE chunk (lane & 3) ^ ((row >> 2) & 3)
   int a_nb[RQA], a_bh[RQA], a_bw[RQA];
   unsigned a_c16[RQA], b_voff[RQB];
   STCAT_UNROLL
   for (int i = 0; i < RQA; ++i) {
-    const int q = wave + 8 * i, r = q * 16 + (lane >> 2), m = m0 + r;
+    const int q = wave + NW * i, r = q * 16 + (lane >> 2), m = m0 + r;
     a_c16[i] = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16);
     a_nb[i] = -1; a_bh[i] = 0; a_bw[i] = 0;
     if (q < QA && m < Mc) {
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
   }
   STCAT_UNROLL
   for (int i = 0; i < RQB; ++i) {
-    const int q = wave + 8 * i, r = q * 16 + (lane >> 2);
+    const int q = wave + NW * i, r = q * 16 + (lane >> 2);
     b_voff[i] = q < QB ? (unsigned)(((n0 + r) * p.ldb) * 2 + ((lane & 3) ^ ((r >> 2) & 3)) * 16) : STCAT_BUF_OOB;
   }
   const __bf16* Ap[3] = {p.Ah, p.Al, stcat_plane(p.Ah, p.Al, 2)};
@@ -268,17 +271,17 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
       h_ >>= dshift; w_ >>= dshift;                                                                     \
       ok_ = ok_ & ((unsigned)h_ < (unsigned)g.H) & ((unsigned)w_ < (unsigned)g.W);                      \
       const unsigned vo_ = ok_ ? (unsigned)(((a_nb[i] * g.H + h_) * g.W + w_) * g.ld) * 2u + a_c16[i] : STCAT_BUF_OOB; \
-      if ((QA % 8 == 0) || wq + 8 * i < QA) {                                                          \
+      if ((QA % NW == 0) || wq + NW * i < QA) {                                                          \
         STCAT_UNROLL                                                                                    \
-        for (int pi_ = 0; pi_ < NPL; ++pi_) stcat_glds16(dA_[pi_], base_ + pi_ * PLANE_A + i * 8192, vo_, soA_); \
+        for (int pi_ = 0; pi_ < NPL; ++pi_) stcat_glds16(dA_[pi_], base_ + pi_ * PLANE_A + i * (NW * 1024), vo_, soA_); \
       }                                                                                                 \
     }                                                                                                   \
     STCAT_UNROLL                                                                                        \
     for (int i = 0; i < RQB; ++i) {                                                                     \
-      if ((QB % 8 == 0) || wq + 8 * i < QB) {                                                          \
+      if ((QB % NW == 0) || wq + NW * i < QB) {                                                          \
         STCAT_UNROLL                                                                                    \
         for (int pi_ = 0; pi_ < NPL; ++pi_)                                                             \
-          stcat_glds16(dB_[pi_], base_ + NP * PLANE_A + pi_ * PLANE_B + i * 8192, b_voff[i], soB_);     \
+          stcat_glds16(dB_[pi_], base_ + NP * PLANE_A + pi_ * PLANE_B + i * (NW * 1024), b_voff[i], soB_);     \
       }                                                                                                 \
     }                                                                                                   \
     /* K order: channel chunk OUTER, filter tap INNER — the 9 taps of a 3x3 filter re-read the same pixels shifted  \
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(512) igemm_pl_fwd_kernel(PlParams p) {
 
   STCAT_PL_ACC_INIT
   constexpr int NMMA = (F32 ? 4 : PlProd<NP>::N) * TM * TN, NRD = NPL * (TM + TN);
-  constexpr int NDMA = NPL * ((QA >= 8 ? RQA : 1) + (QB >= 8 ? RQB : 1));
+  constexpr int NDMA = NPL * ((QA >= NW ? RQA : 1) + (QB >= NW ? RQB : 1));
   Frag fa, fb;
   STCAT_PL_STAGE_LOAD(0)
   STCAT_PL_STAGE_LOAD(1)

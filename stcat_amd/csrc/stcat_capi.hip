@@ -316,12 +316,13 @@ int pl_prepare(K kernel, int lds_bytes) {
     STCAT_LAUNCH((KERNEL<BM_, BN_, WM_, WN_>), GRID, dim3(512), lds_, st, p);                          \
   }
 // three-plane (mode 5) instantiations: 6 x (BM + BN) x 64 bytes of LDS for the two stages
-#define STCAT_PL3_FWD(BM_, BN_, WM_, WN_, GRID)                                                        \
-  {                                                                                                    \
-    constexpr int lds_ = 6 * (BM_ + BN_) * 64;                                                         \
-    if (int rc_ = pl_prepare(igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3>, lds_)) return rc_;     \
-    STCAT_LAUNCH((igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3>), GRID, dim3(512), lds_, st, p);   \
+#define STCAT_PL3_FWD_NW(BM_, BN_, WM_, WN_, NW_, GRID)                                                         \
+  {                                                                                                            \
+    constexpr int lds_ = 6 * (BM_ + BN_) * 64;                                                                 \
+    if (int rc_ = pl_prepare(igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3, NW_>, lds_)) return rc_;        \
+    STCAT_LAUNCH((igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 3, NW_>), GRID, dim3(64 * NW_), lds_, st, p); \
   }
+#define STCAT_PL3_FWD(BM_, BN_, WM_, WN_, GRID) STCAT_PL3_FWD_NW(BM_, BN_, WM_, WN_, 8, GRID)
 #define STCAT_PL3_WGRAD(BM_, BN_, WM_, WN_, GRID)                                                      \
   {                                                                                                    \
     constexpr int lds_ = 6 * (BM_ + BN_) * 64;                                                         \
@@ -334,18 +335,27 @@ int g_pl_force = -1;  // stcat_debug_force_pl_tile: index into the tile table be
 struct PlTile { int bm, bn; float eff; };
 // relative cost per MAC of each tile shape (bigger wave tiles amortise fragment reads and DMA issue better)
 // (224 x 256: 7 x 32 rows, 8 waves side by side — 50176 = 224 * 224 rows of layer3 fill 224 of 256 CUs in ONE round)
-const PlTile kPlTiles[6] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f},
-                            {224, 256, 1.04f}};
+// (128 x 64, index 6: three planes only — 4 waves, 74 KB of LDS, two workgroups per CU; chosen by rule, not by cost)
+const PlTile kPlTiles[7] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.12f}, {128, 128, 1.30f}, {256, 64, 1.35f},
+                            {224, 256, 1.04f}, {128, 64, 1.60f}};
 
 // mode 5 (three planes): two stages of 3 x (BM + BN) x 64 bytes must fit 160 KB -> BM + BN <= 384; the six-term
 // contraction issues 24 MFMAs per k-step against 12 fragment reads on the 64 x 64 wave tile of the 256 x 128 shapes
-const float kPl3Eff[6] = {0.f, 1.00f, 1.00f, 1.15f, 1.20f, 0.f};   // indexed like kPlTiles; 0 = not available
-int pick_pl3_tile(int M, int N) {
+const float kPl3Eff[7] = {0.f, 1.00f, 1.00f, 1.15f, 1.20f, 0.f, 1.60f};   // indexed like kPlTiles; 0 = not available
+int g_pl3_small = 0;   // stcat_debug_pl_flags bit 2 sets it: the two-workgroup 128 x 64 tile for short reductions
+int pick_pl3_tile(int M, int N, int K) {
   if (g_pl_force >= 0) {
     int f = g_pl_force;
     if (kPl3Eff[f] == 0.f) f = 1;                         // 256x256 / 224x256 do not exist with three planes
     if (N % kPlTiles[f].bn == 0) return f;
   }
+  // Short reductions (K <= 512: the 1x1 expand / reduce convs and their data gradients): the epilogue's HBM traffic
+  // (residual planes in, three planes + bit mask out) takes as long as the K loop, and with ONE workgroup per CU nothing
+  // overlaps them.  The 4-wave 128 x 64 tile lets two workgroups share the CU — MEASURED NEUTRAL in isolation (256 -> 1024
+  // forward 0.264 vs 0.267 ms, data gradient 0.198 vs 0.195, step-like operands) and 3.4 ms SLOWER per C3 step (its
+  // 32 x 64 wave tiles read LDS twice as often per MFMA and the launches that run beside the weight-gradient stream lose
+  // more than the overlap gains; profiles/r03_tile6_experiment.log): opt-in through stcat_debug_pl_flags(4) only.
+  if (g_pl3_small && K <= 512 && N % 64 == 0 && (long)M * N >= (1l << 22)) return 6;
   int best = -1;
   float best_cost = 0.f;
   for (int i = 1; i <= 4; ++i) {
@@ -389,7 +399,7 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   // stride-2 data gradient on even dims: parity-class row order (igemm_pl.h, PlParams::par): 4 x tiles(M / 4)
   p.par = (p.g.div == 2 && p.g.mul == 1 && p.g.sgn == -1 && p.g.OH % 2 == 0 && p.g.OW % 2 == 0 && !(g_pl_debug & 4)) ? 1 : 0;
   const int Mrows = p.par ? p.M / 4 : p.M;
-  const int ti = g_pl_np == 3 ? pick_pl3_tile(p.par ? p.M : Mrows, p.N) : pick_pl_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K);
+  const int ti = g_pl_np == 3 ? pick_pl3_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K) : pick_pl_tile(p.par ? p.M : Mrows, p.N, p.par ? p.K / 4 : p.K);
   if (ti < 0) return fail("plane GEMM: N = %d is not a multiple of 64", p.N);
   const int BM = kPlTiles[ti].bm, BN = kPlTiles[ti].bn;
   const dim3 grid((p.par ? 4 : 1) * cdiv(Mrows, BM) * (p.N / BN));
@@ -398,6 +408,7 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
       case 1: STCAT_PL3_FWD(256, 128, 4, 2, grid) break;
       case 2: STCAT_PL3_FWD(128, 256, 2, 4, grid) break;
       case 3: STCAT_PL3_FWD(128, 128, 2, 4, grid) break;
+      case 6: STCAT_PL3_FWD_NW(128, 64, 2, 2, 4, grid) break;
       default: STCAT_PL3_FWD(256, 64, 8, 1, grid) break;
     }
     return launch_status();
@@ -1070,13 +1081,14 @@ int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out,
 
 // ---- plane-format backbone (mma mode 4): every tensor is a pair of bf16 planes (hi, lo) ------------------------
 int stcat_debug_force_pl_tile(int index) {
-  if (index < -1 || index > 5) return fail("debug_force_pl_tile: index must be -1 .. 5");
+  if (index < -1 || index > 6) return fail("debug_force_pl_tile: index must be -1 .. 6");
   g_pl_force = index;
   return 0;
 }
 
 int stcat_debug_pl_flags(int flags) {
-  g_pl_debug = flags;
+  g_pl_debug = flags & 3;
+  g_pl3_small = (flags & 4) ? 1 : 0;   // bit 2: three-plane short reductions on the two-workgroup 128 x 64 tile
   return 0;
 }
 

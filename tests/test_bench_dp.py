@@ -75,7 +75,7 @@ def test_bench_default_line_is_fp32_class_and_one_launch_mode():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     assert d["dtype"].startswith("f32-class") and "launch_modes" not in d
-    assert d["config"]["launch"] == "eager (launch by launch)"
+    assert d["config"]["launch"].startswith("launch plans")      # round 3: composite nodes replayed by one C call each
     assert d["throughput_mode"]["mma"].startswith("3 bf16 cross terms") and d["throughput_mode"]["steps"] == 10
     assert d["exact_f32_mode"]["steps"] == 10 and d["exact_f32_mode"]["warmup"] == 3
     assert d["kernels"]["stcat_weight_planes_multi"]["launches"] == 1

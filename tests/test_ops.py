@@ -261,6 +261,11 @@ def _pl_conv(dev, big):
     _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=3, mode="bf16x6p")
     _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2, mode="bf16x6p")
     _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0, mode="bf16x6p")
+    # tile 6: 128 x 64 with FOUR waves (two workgroups per CU; the K <= 512 1x1 convolutions of mode bf16x6p): residual,
+    # ragged tail, the parity-class data gradient, 3x3 taps
+    _pl_conv_case(dev, 2, 9, 7, 128, 128, 1, 1, 0, relu=True, res=True, tile=6, mode="bf16x6p")
+    _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=6, mode="bf16x6p")
+    _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=6, wgrad=False, mode="bf16x6p")
     if big:
         for m3 in ("bf16x6p",):
             _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, mode=m3)

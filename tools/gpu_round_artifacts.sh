@@ -2,7 +2,7 @@
 # Round artifacts on the GPU box: full GPU test-suite, smoke, the bench line, rocprofv3 kernel stats, PMC HBM traffic +
 # MFMA utilisation (own passes), device timeline, host profile / phase times, step-like GEMM table, comm-mode lines.
 # Everything lands under gpurun_out/$TAG; the summaries worth judging are copied into profiles/ afterwards.
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/$TAG
 mkdir -p $O
 R=$PWD
@@ -23,7 +23,7 @@ P='import json,sys; d=json.loads(sys.stdin.readline()); print({k:d.get(k) for k 
 } > $O/bench_variants.log 2>&1; cat $O/bench_variants.log
 timeout 300 python tools/host_profile.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.log
 timeout 300 python tools/phase_times.py 2>&1 | grep -v amdgpu.ids | tail -6 >> $O/host_profile.log; tail -6 $O/host_profile.log
-timeout 300 python tools/bench_gemm.py --mma bf16x3p --step-like 2>&1 | grep -v amdgpu.ids > $O/plane_gemm_steplike.log; tail -3 $O/plane_gemm_steplike.log
+timeout 300 python tools/bench_gemm.py --mma bf16x6p --step-like 2>&1 | grep -v amdgpu.ids > $O/plane_gemm_steplike.log; tail -3 $O/plane_gemm_steplike.log
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$TAG -o p -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2>&1
