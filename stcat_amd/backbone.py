@@ -20,7 +20,10 @@ from torch.autograd import Function
 from . import ops, plans
 from .misc import NestedTensor
 
+import os
+
 BLOCKS = (3, 4, 23, 3)
+FORWARD_CHAINS = not os.environ.get("STCAT_NO_FORWARD_CHAINS")   # the plane-format forward as two half-clip chains
 PLANES = (64, 128, 256, 512)
 
 
@@ -218,6 +221,46 @@ class _BackboneFnPl(Function):
         wp, wt = body._wpl_cache.refresh(ws, transposed=need_bwd, tscales=ts)
         tape = []
         yf = None
+        # Two frame ranges, two streams (FORWARD_CHAINS): every conv of the forward pass is issued once per half of the
+        # clip, the halves on their own streams, both writing into ONE whole-batch output (the backward pass is
+        # unchanged).  A launch of the forward pass fills the 256 CUs unevenly (layer3, N = 256: 392 tiles = 1.53 rounds)
+        # and alternates between an MFMA-bound K loop and an HBM-bound epilogue; with two independent chains the idle
+        # CUs and the idle pipe of one launch are taken by the other chain's launch.
+        n_all = x.shape[0]
+        chains = [(0, n_all)]
+        fork = None
+        if FORWARD_CHAINS and n_all >= 8 and x.t.is_cuda:
+            chains = [(0, n_all // 2), (n_all // 2, n_all)]
+            fork = ops.fork_stream(x.t)
+
+        def conv(xin, w_, s_, b_, res, stride, pad, relu, planes_out=True, f32_out=False, want_mask=False):
+            if fork is None or not fork.active:
+                return ops.pl_conv_fwd_raw(xin, w_, s_, b_, res, stride, pad, relu, planes_out=planes_out, f32_out=f32_out,
+                                           want_mask=want_mask)
+            n, H, W, _ = xin.shape
+            Cout, KH = w_.shape[0], w_.shape[1]
+            OH, OW = ops.conv_out_hw(H, W, KH, stride, pad)
+            yp = ops.Planes.empty(xin.t, n, OH, OW, Cout) if planes_out else None
+            yf_ = torch.empty(n, OH, OW, Cout, device=xin.device, dtype=torch.float32) if f32_out else None
+            if want_mask and yp is not None:
+                yp.mask = torch.empty(n * OH * OW, Cout // 8, device=xin.device, dtype=torch.uint8)
+            for t_ in (yp.t if yp is not None else None, yp.mask if yp is not None else None, yf_):
+                if t_ is not None:     # allocated on the main stream, written / read by the second chain as well
+                    t_.record_stream(fork.side)
+                    if ops.L.RECORDER is not None:
+                        ops.L.RECORDER.keep.append(t_)
+            for ci, (a, b) in enumerate(chains):
+                o = (yp.frames(a, b) if yp is not None else None, yf_[a:b] if yf_ is not None else None)
+                args = (xin.frames(a, b), w_, s_, b_, res.frames(a, b) if res is not None else None, stride, pad, relu)
+                if ci == 0:
+                    ops.pl_conv_fwd_raw(*args, out=o)
+                else:
+                    with torch.cuda.stream(fork.side):
+                        ops.pl_conv_fwd_raw(*args, out=o)
+            return yp, yf_
+
+        if fork is not None and fork.active:
+            ops._wait_stream(fork.side, fork.main)     # the second chain starts behind the max-pool / the weight planes
         for bi, (li, blk) in enumerate(blocks):
             last = bi == len(blocks) - 1
             w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
@@ -228,20 +271,23 @@ class _BackboneFnPl(Function):
             # consumer (the next block) is trainable
             tr = need_bwd and blk.conv1.weight.requires_grad
             tr_next = need_bwd and not last and blocks[bi + 1][1].conv1.weight.requires_grad
-            o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True, want_mask=tr)
-            o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True, want_mask=tr)
+            o1, _ = conv(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True, want_mask=tr)
+            o2, _ = conv(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True, want_mask=tr)
             wd = sd = None
             if blk.downsample is not None:
                 wd = _ohwi(blk.downsample[0].weight)
                 sd, bd = blk.downsample[1].folded()
-                idt, _ = ops.pl_conv_fwd_raw(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
+                idt, _ = conv(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
             else:
                 idt = x
-            y, yf = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last,
-                                        want_mask=tr_next)
+            y, yf = conv(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last,
+                         want_mask=tr_next)
             if need_bwd and blk.conv1.weight.requires_grad:
                 tape.append((blk, x, o1, o2, yf if last else y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
             x = y
+        if fork is not None and fork.active:
+            ops._wait_stream(fork.main, fork.side)
+            yf.record_stream(fork.main)
         ctx.tape = tape
         ctx.wt = wt
         ctx.body = body

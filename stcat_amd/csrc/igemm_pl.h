@@ -389,13 +389,14 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
       if (mrow < Mc && !(p.debug & 2)) {
         if (p.Rh) {
           STCAT_UNROLL
-          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = *reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n);
+          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = STCAT_LOAD_STREAM(reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n));
         }
         if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
       }
     }
   };
-  constexpr bool DB = !(BM == 256 && BN == 256) && !(NP == 3 && TM * TN >= 4);   // (no registers left for the second set)
+  // (the 256 x 256 two-plane tile has no registers left for the second set; the three-plane 256 x 128 tile does: 212 VGPRs)
+  constexpr bool DB = !(BM == 256 && BN == 256);
   if (DB) prefetch(pre[0], 0);
   STCAT_UNROLL
   for (int tm = 0; tm < TM; ++tm) {
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
           bf16x8 o8[NP];
           stcat_split8n<NP>(x, o8);
           STCAT_UNROLL
-          for (int pi = 0; pi < NP; ++pi) *reinterpret_cast<bf16x8*>(Cp[pi] + (long)m * p.ldc + n) = o8[pi];
+          for (int pi = 0; pi < NP; ++pi) STCAT_STORE_STREAM(reinterpret_cast<bf16x8*>(Cp[pi] + (long)m * p.ldc + n), o8[pi]);
         }
         if (p.Cf) {
           stcat_st4(p.Cf + (long)m * p.ldc + n, make_float4(x[0], x[1], x[2], x[3]));

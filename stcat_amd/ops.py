@@ -1136,9 +1136,18 @@ class Planes:
     __slots__ = ("t", "mask")
 
     def __init__(self, t: torch.Tensor, mask: Optional[torch.Tensor] = None):
-        assert t.dtype == _bf16 and t.shape[0] == L.plane_count() and t.is_contiguous(), (t.dtype, t.shape, L.get_mma_mode())
+        # every plane dense; the planes equally spaced (a frame range of a whole-batch allocation is a valid plane set)
+        assert t.dtype == _bf16 and t.shape[0] == L.plane_count() and t[0].is_contiguous(), (t.dtype, t.shape, L.get_mma_mode())
         self.t = t
         self.mask = mask  # optional bit mask (x > 0), uint8 [rows, C / 8], written by the producing conv epilogue
+
+    def frames(self, a: int, b: int) -> "Planes":
+        """frames a..b of an image plane set [NP, n, H, W, C] as a view (mask rows likewise)"""
+        m = None
+        if self.mask is not None:
+            rows = self.t.shape[2] * self.t.shape[3]
+            m = self.mask[a * rows:b * rows]
+        return Planes(self.t[:, a:b], m)
 
     @staticmethod
     def empty(like: torch.Tensor, *shape) -> "Planes":
@@ -1161,7 +1170,7 @@ class Planes:
 
     @property
     def l(self) -> int:
-        return self.t.data_ptr() + self.t[0].numel() * 2
+        return self.t.data_ptr() + self.t.stride(0) * 2
 
 
 def _pl(p: Optional[Planes]):
@@ -1191,16 +1200,20 @@ def pl_maxpool_raw(x: torch.Tensor) -> Planes:
 
 
 def pl_conv_fwd_raw(x: Planes, w: Planes, scale, bias, res: Optional[Planes], stride, pad, relu, planes_out=True,
-                    f32_out=False, want_mask=False):
+                    f32_out=False, want_mask=False, out=None):
     """w: planes of the OHWI weight [Cout,KH,KW,Cin].  Returns (y planes | None, y fp32 | None); with want_mask the
-    planes carry the bit mask (y > 0) for the backward pass."""
+    planes carry the bit mask (y > 0) for the backward pass.  out = (planes | None, fp32 | None): write there (a frame
+    range of a whole-batch allocation) instead of allocating."""
     n, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH, OW = conv_out_hw(H, W, KH, stride, pad)
-    yp = Planes.empty(x.t, n, OH, OW, Cout) if planes_out else None
-    yf = torch.empty(n, OH, OW, Cout, device=x.device, dtype=_f32) if f32_out else None
-    if want_mask and yp is not None:
-        yp.mask = torch.empty(n * OH * OW, Cout // 8, device=x.device, dtype=torch.uint8)
+    if out is not None:
+        yp, yf = out
+    else:
+        yp = Planes.empty(x.t, n, OH, OW, Cout) if planes_out else None
+        yf = torch.empty(n, OH, OW, Cout, device=x.device, dtype=_f32) if f32_out else None
+        if want_mask and yp is not None:
+            yp.mask = torch.empty(n * OH * OW, Cout // 8, device=x.device, dtype=torch.uint8)
     L.call("stcat_pl_conv_fwd", x.h, x.l, w.h, w.l, L._ptr(scale), L._ptr(bias), *_pl(res), *_pl(yp), L._ptr(yf),
            L._ptr(yp.mask if yp is not None else None), n, H, W, Cin, Cout, KH, KW, stride, pad, int(relu),
            L.stream_of(x.t))
