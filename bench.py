@@ -594,8 +594,35 @@ def main():
                 run_once()
             fence()
             loader[f"ms_per_step_with_{key}_h2d"] = round(1e3 * (time.perf_counter() - t1) / 5, 2)
+        # ... and with the copy OFF the compute stream: copy stream + two resident device buffers (stcat_amd/loader.py),
+        # clip k + 1 is uploaded while clip k computes
+        from stcat_amd.loader import DeviceFramePrefetcher
+
+        def clips(host, n):
+            for _ in range(n):
+                yield host
+        for key, host in (("uint8", u8_host), ("fp32", f32_host)):
+            def run_on(dev_frames):
+                reducer.zero_grad()
+                ops.dropout_begin_step(dev)
+                arena.reset()
+                out = model(NestedTensor(dev_frames, mask, [T]), ["synthetic"])
+                losses = criterion(out, targets, [T], plan=plan)
+                total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
+                total.backward()
+                reducer.finish()
+            pf = DeviceFramePrefetcher(clips(host, 12), dev)
+            for i_, fr in enumerate(pf):
+                if i_ == 5:
+                    fence()
+                    t1 = time.perf_counter()
+                run_on(fr)
+            fence()
+            loader[f"ms_per_step_with_{key}_h2d_overlapped"] = round(1e3 * (time.perf_counter() - t1) / 7, 2)
         loader["note"] = ("frames uploaded from pinned host memory inside every step (PCIe Gen5 x16); uint8 = decoder "
-                          "output [T,H,W,3], normalised inside the stem kernel; fp32 = the reference's normalised [T,3,H,W]")
+                          "output [T,H,W,3], normalised inside the stem kernel; fp32 = the reference's normalised [T,3,H,W]; "
+                          "_overlapped = the same upload on a copy stream into two resident buffers while the "
+                          "previous step computes (stcat_amd/loader.py)")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N=1 only: other ranks would idle at the barrier

