@@ -168,9 +168,9 @@ class _BackboneFn(Function):
         # weight gradients on a second stream behind the data-gradient chain (see _BackboneFnPl.backward)
         wg = ops.WgradStream(dy)
 
-        def wgrad(key, g, xin, wshape, stride, pad):
+        def wgrad(param, g, xin, wshape, stride, pad):
             with wg:
-                grads[key] = ops.conv_wgrad_raw(g, xin, wshape, stride, pad)
+                grads[id(param)] = ops.conv_wgrad_raw(g, xin, wshape, stride, pad)
             wg.keep(g, xin)
 
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]

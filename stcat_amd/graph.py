@@ -26,6 +26,12 @@ class GraphedStep:
         """step_fn: the compute part of one step (no collectives, no host syncs); returns the loss tensor.
         Runs `warmup` eager iterations on a side stream (allocator / lazy-init warm-up), then captures one."""
         device = torch.device(device)
+        # Round 3 replaced this path by launch plans (stcat_amd/plans.py); its newer multi-stream schedules — the two
+        # forward chains of the backbone, the deferred weight gradients of the grounding model — record allocator
+        # stream uses that a capture cannot carry, so a captured step runs the round-2 schedule.
+        from . import backbone, composite
+        backbone.FORWARD_CHAINS = 1
+        composite.DEFER_WGRADS = False
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
