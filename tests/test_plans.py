@@ -8,7 +8,7 @@ import torch
 from stcat_amd import _lib, ops, plans, synth
 from stcat_amd.misc import BoxList, NestedTensor
 from stcat_amd.pipeline import SyntheticText, build_model
-from tests.backends import both, use_emu
+from tests.backends import use_emu
 
 
 def _build(dev, L=5, train=False):
@@ -101,16 +101,59 @@ def _check_equal(ref, got, tol, grad_l2=None):
                 _same(g2[n], g1[n], f"step {k} grad {n}", tol)
 
 
-@both
-def _plans_replay_equals_eager(dev, big):
+def _guard_rails(dev, model, criterion, wd, T, res):
+    """on a model whose plans exist (>= 3 steps ran)"""
+    # (1) a second forward while the first one's backward is outstanding runs eagerly: static buffers stay intact
+    for p in model.parameters():
+        p.grad = None
+    before = plans.STATS["eager"]
+    out1 = model(_clip(dev, T, res, 0), ["synthetic"])
+    keep = out1["pred_boxes"].detach().clone()
+    out2 = model(_clip(dev, T, res, 1), ["synthetic"])
+    assert plans.STATS["eager"] > before
+    assert torch.equal(out1["pred_boxes"].detach(), keep)
+    assert not torch.equal(out2["pred_boxes"].detach(), keep)
+    del out1, out2
+    # (2) gradients kept across steps alias the plans' static buffers: refused, not silently doubled
+    _step(model, criterion, wd, _clip(dev, T, res, 2), T, res, dev)
+    out = model(_clip(dev, T, res, 3), ["synthetic"])
+    act, tb = synth.synth_targets(T)
+    losses = criterion(out, [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}], [T])
+    with pytest.raises((_lib.StcatHipError, RuntimeError), match="zero_grad"):
+        sum(losses[k] * wd[k] for k in losses).backward()
+
+
+def test_emu_plans_replay_equals_eager_and_guard_rails():
+    """3 steps on 3 different clips (one padded): step 0 eager, step 1 recorded, step 2 replayed — equal to the eager
+    run; then the guard rails on the same model (one model build: the emulator is slow)"""
+    dev = use_emu()
+    T, res = 2, 32
+    ref, _ = _run(dev, T, res, 3, False)
+    plans.clear()
+    plans.enable(True)
+    plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0)
+    try:
+        ops.manual_seed(7)
+        model, criterion, wd = _build(dev)
+        got = [_step(model, criterion, wd, _clip(dev, T, res, k), T, res, dev) for k in range(3)]
+        assert plans.STATS["recorded"] >= 8 and plans.STATS["replayed"] >= plans.STATS["recorded"], plans.STATS
+        _check_equal(ref, got, 2e-5)
+        _guard_rails(dev, model, criterion, wd, T, res)
+    finally:
+        plans.enable(False)
+        plans.clear()
+
+
+@pytest.mark.gpu
+def test_gpu_plans_replay_equals_eager():
     """4 steps on 4 different clips (two of them padded): step 0 eager, step 1 recorded, steps 2-3 replayed"""
-    T, res = (8, 224) if big else (2, 32)
-    mma = "bf16x6p" if big else "f32"
-    ref, _ = _run(dev, T, res, 4, False, mma=mma)
-    got, stats = _run(dev, T, res, 4, True, mma=mma)
+    from tests.backends import use_hip
+    dev = use_hip()
+    ref, _ = _run(dev, 8, 224, 4, False, mma="bf16x6p")
+    got, stats = _run(dev, 8, 224, 4, True, mma="bf16x6p")
     assert stats["recorded"] >= 8 and stats["replayed"] >= 2 * stats["recorded"], stats
     # the weight gradients are sums of atomically ordered split-K partials: run-to-run differences of a few ulp
-    _check_equal(ref, got, 2e-4 if big else 2e-5, grad_l2=3e-3 if big else None)
+    _check_equal(ref, got, 2e-4, grad_l2=3e-3)
 
 
 @pytest.mark.gpu
@@ -127,38 +170,6 @@ def test_gpu_plans_train_mode_dropout():
     # and the masks differ from step to step (same clip shape, different losses even on the same clip is not tested
     # here; the counter base advanced: the host offset restarts while the device base moved on)
     assert ref[2][1] != ref[3][1]
-
-
-def test_emu_plans_guard_rails():
-    dev = use_emu()
-    plans.clear()
-    plans.enable(True)
-    try:
-        model, criterion, wd = _build(dev)
-        T, res = 2, 32
-        for k in range(3):
-            _step(model, criterion, wd, _clip(dev, T, res, k), T, res, dev)
-        # (1) a second forward while the first one's backward is outstanding runs eagerly: static buffers stay intact
-        for p in model.parameters():
-            p.grad = None
-        before = plans.STATS["eager"]
-        out1 = model(_clip(dev, T, res, 0), ["synthetic"])
-        keep = out1["pred_boxes"].detach().clone()
-        out2 = model(_clip(dev, T, res, 1), ["synthetic"])
-        assert plans.STATS["eager"] > before
-        assert torch.equal(out1["pred_boxes"].detach(), keep)
-        assert not torch.equal(out2["pred_boxes"].detach(), keep)
-        del out1, out2
-        # (2) gradients kept across steps alias the plans' static buffers: refused, not silently doubled
-        _step(model, criterion, wd, _clip(dev, T, res, 2), T, res, dev)
-        out = model(_clip(dev, T, res, 3), ["synthetic"])
-        act, tb = synth.synth_targets(T)
-        losses = criterion(out, [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}], [T])
-        with pytest.raises((_lib.StcatHipError, RuntimeError), match="zero_grad"):
-            sum(losses[k] * wd[k] for k in losses).backward()
-    finally:
-        plans.enable(False)
-        plans.clear()
 
 
 def test_plan_table_covers_every_launch_entry_point():
