@@ -341,7 +341,9 @@ const PlTile kPlTiles[7] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.1
 
 // mode 5 (three planes): two stages of 3 x (BM + BN) x 64 bytes must fit 160 KB -> BM + BN <= 384; the six-term
 // contraction issues 24 MFMAs per k-step against 12 fragment reads on the 64 x 64 wave tile of the 256 x 128 shapes
-const float kPl3Eff[7] = {0.f, 1.00f, 1.00f, 1.15f, 1.20f, 0.f, 1.60f};   // indexed like kPlTiles; 0 = not available
+// (128 x 256 reads each A row block once instead of twice when N = 256 and measured 3-5 % ahead of 256 x 128 on every
+// layer3 shape — step-like operands: 3x3 forward 0.380 -> 0.363 ms, 1024 -> 256 forward 0.195 -> 0.185 ms)
+const float kPl3Eff[7] = {0.f, 1.00f, 0.97f, 1.15f, 1.20f, 0.f, 1.60f};   // indexed like kPlTiles; 0 = not available
 int g_pl3_small = 0;   // stcat_debug_pl_flags bit 2 sets it: the two-workgroup 128 x 64 tile for short reductions
 int pick_pl3_tile(int M, int N, int K) {
   if (g_pl_force >= 0) {
