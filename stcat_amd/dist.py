@@ -221,7 +221,10 @@ class GradBucketReducer:
         b["pending"] = -1
 
     def _on_grad(self, p):
-        if self.deferred:
+        # (the post-accumulate hook also fires for a parameter whose node returned None because it was handed over through
+        # early(): that one is counted already — counting it again would complete mixed buckets too soon and leave the
+        # late bucket below zero, never reduced)
+        if self.deferred or p in self._early:
             return
         b = self.buckets[self._owner[p]]
         b["pending"] -= 1

@@ -337,7 +337,7 @@ class _ShimCtx:
 
 class _Entry:
     __slots__ = ("calls", "fwd", "bwd", "ctx", "outs", "pool", "live", "done", "single", "params", "grad_ptrs", "gsig",
-                 "spec")
+                 "spec", "param_pos")
 
     def __init__(self):
         self.calls = 0
@@ -350,6 +350,7 @@ class _Entry:
         self.done = True
         self.single = False
         self.params = None
+        self.param_pos = None
         self.grad_ptrs = set()
 
 
@@ -464,6 +465,7 @@ class PlannedFn(Function):
         tensors = [a for a in args if torch.is_tensor(a)]
         ctx.entry = e
         ctx.ext = tensors
+        ctx.args = args
         e.live = weakref.ref(ctx)
         e.done = False
         if e.fwd is None:
@@ -477,6 +479,7 @@ class PlannedFn(Function):
             outs_t = (outs,) if e.single else tuple(outs)
             e.outs = tuple(o.detach() if torch.is_tensor(o) else o for o in outs_t)
             e.params = [a for a in args if torch.is_tensor(a) and _is_param(a)]
+            e.param_pos = [i for i, a in enumerate(args) if torch.is_tensor(a) and _is_param(a)]
         else:
             e.fwd.run(tensors)
             outs_t = tuple(o.detach() if torch.is_tensor(o) else o for o in e.outs)
@@ -500,6 +503,7 @@ class PlannedFn(Function):
             raise L.StcatHipError("launch plan: backward ran twice for one forward (retain_graph is not supported; "
                                   "disable plans with stcat_amd.plans.enable(False))")
         gouts = tuple(g if (g is None or g.is_contiguous()) else g.contiguous() for g in gouts)
+        ctx_args = ctx.args
         for p in e.params:
             if p.grad is not None and p.grad.data_ptr() in e.grad_ptrs:
                 raise L.StcatHipError(
@@ -520,7 +524,21 @@ class PlannedFn(Function):
             plan.run(ext)
             grads = tuple(g.detach() if torch.is_tensor(g) else g for g in static)
         e.done = True
+        # Data-parallel run: hand the node's parameter gradients to the reducer in ONE call, from the stream that wrote
+        # them, and return None for them — no AccumulateGrad node and no per-parameter Python hook runs for ~95 % of the
+        # model's parameters (round 2: ~1000 hook calls on the autograd thread per step delayed the next node's launch;
+        # a live process group cost 3.7 ms per step at one rank, profiles/r03_bench_variants.log)
+        from . import ops
+        sink = ops.GRAD_SINK
+        if sink is not None and e.param_pos:
+            pos = [i for i in e.param_pos if torch.is_tensor(grads[i])]
+            if pos and sink.early([ctx_args[i] for i in pos], [grads[i] for i in pos]):
+                gl = list(grads)
+                for i in pos:
+                    gl[i] = None
+                grads = tuple(gl)
         ctx.ext = None
+        ctx.args = None
         return (None,) + grads
 
 

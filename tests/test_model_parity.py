@@ -356,6 +356,21 @@ def test_gpu_c1_forward_backward(golden_dir):
     norms = dict(zip([str(n) for n in g["grad/names"]], g["grad/norms"]))
     for n_, gr in grads.items():
         assert abs(gr.norm().item() - float(norms[n_])) <= 1e-2 * max(1.0, float(norms[n_])), n_
+    # the eleven gradients the fixture holds in full (one per family, layer2.0 .. the heads): tensor against tensor.
+    # The bound is what separates two fp32 evaluations of this chain at C1 (the fp32 CPU reference itself sits 1.2e-2 /
+    # 2.5e-2 from an fp64 run on layer2 / layer3 tensors: single ReLU-kink flips among 8 x 28 x 28 samples): 3e-2 rel-L2
+    # for the backbone, 5e-3 elsewhere; structurally zero gradients (key-side biases) get the absolute floor.
+    full = [k[len("grad/full/"):] for k in g.files if k.startswith("grad/full/")]
+    assert len(full) >= 11
+    for n_ in full:
+        ref = torch.from_numpy(g["grad/full/" + n_]).double()
+        hip_name = "ground_decoder.decoder." + n_ if n_.startswith("bbox_embed.") and n_ not in grads else n_
+        got = grads[hip_name].double().reshape(-1)
+        if got.numel() > ref.numel():            # the fixture keeps a flat-stride sub-sample of large tensors
+            got = got[::-(-got.numel() // (1 << 16))]
+        assert got.shape == ref.shape, n_
+        err = (got - ref).norm().item() / (ref.norm().item() + GRAD_ABS_FLOOR * ref.numel() ** 0.5 / GRAD_TOL)
+        assert err <= (3e-2 if n_.startswith("vis_encoder.") else 5e-3), f"golden gradient {n_}: rel-L2 {err:.2e}"
 
 
 @pytest.mark.gpu
