@@ -129,6 +129,9 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
                 f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). stcat_amd has no CPU/PyTorch fallback.")
         _lib = _bind(ctypes.CDLL(path))
+        flags = os.environ.get("STCAT_PL_FLAGS")       # timing experiments only (stcat_debug_pl_flags: A/B of kernel variants)
+        if flags:
+            _lib.stcat_debug_pl_flags(int(flags))
     return _lib
 
 
