@@ -299,7 +299,8 @@ def main():
     if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            from stcat_amd.dist import init_rccl_process_group
+            init_rccl_process_group(dev)
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -636,6 +637,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 2),
             "host_cpu_ms_per_step": round(1e3 * host_cpu_s / args.steps, 2),
             "host_cpus": host_cpus,
+            "streams": ops.PICK_REPORT.get(str(dev)),
             "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",

@@ -38,6 +38,10 @@ int stcat_debug_force_tile(int bm, int bn);
 /* stream-K scheduling of the split-bf16 forward GEMM (opt-in experiment): 1 whenever legal,
  * 0 / -1 off (default) */
 int stcat_debug_streamk(int mode);
+/* one workgroup that spins for `microseconds` of wall clock on `stream`: the probe of stcat_amd.ops.pick_streams()
+ * (HIP maps the streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues; two streams that share a queue
+ * serialise, and which ones share depends on what else — RCCL, the framework — created streams before us) */
+int stcat_spin(int microseconds, void* stream);
 
 /* ---- backbone: torchvision ResNet-101 + FrozenBatchNorm2d (models/vision_model/backbone.py:16-66,
  *      93-121; torch conv2d/max_pool2d underneath) ------------------------------------------------ */

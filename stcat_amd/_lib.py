@@ -79,6 +79,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_debug_pl_flags": "i",
     "stcat_debug_force_tile": "ii",
     "stcat_debug_streamk": "i",
+    "stcat_spin": "is",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
     # launch plans (csrc/launch_plan.h): P = host pointer, u = unsigned 64-bit, S = C string

@@ -28,15 +28,16 @@ FORWARD_CHAINS = 1 if os.environ.get("STCAT_NO_FORWARD_CHAINS") else int(os.envi
 # the same for the data-gradient chain of the backward pass: measured neutral next to the weight-gradient stream
 # (86.9 vs 86.9 ms per C3 step), so opt-in
 BACKWARD_CHAINS = bool(os.environ.get("STCAT_BACKWARD_CHAINS"))
-_CHAIN_STREAMS = {}
 
 
 def _chain_streams(dev, k):
-    """k - 1 extra streams for the forward chains (the first chain runs on the caller's stream)"""
-    have = _CHAIN_STREAMS.setdefault(dev, [])
-    while len(have) < k - 1:
-        have.append(torch.cuda.Stream(device=dev))
-    return have[:k - 1]
+    """k - 1 extra streams for the forward chains (the first chain runs on the caller's stream).  They come from the
+    package's one pool of side streams (ops.side_stream): the forward chains, the forked decoder and the input
+    prefetcher are never busy at the same time, and HIP maps ALL streams of a process onto GPU_MAX_HW_QUEUES = 4
+    hardware queues — a fifth stream shares a queue with another one and the two serialise (measured: with a live RCCL
+    group, whose stream is the fifth, the second forward chain landed on the main stream's queue and the forward lost
+    its overlap, +3.5 ms per step; profiles/r03_hw_queues.log)."""
+    return [ops.side_stream(dev, i) for i in range(k - 1)]
 PLANES = (64, 128, 256, 512)
 
 

@@ -560,6 +560,20 @@ int stcat_debug_streamk(int mode) {
 }
 const char* stcat_last_error(void) { return g_err; }
 
+__global__ void __launch_bounds__(64) spin_kernel(long ticks, int* sink) {
+#ifndef STCAT_EMU
+  const long t0 = (long)wall_clock64();     // constant-rate counter, 100 MHz on gfx950
+  long t = t0;
+  while (t - t0 < ticks) t = (long)wall_clock64();
+  if (sink && t == 0x7fffffffffffffffl) *sink = 1;   // (keeps the loop alive under optimisation)
+#endif
+}
+int stcat_spin(int microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 100000) return fail("spin: 0 .. 100000 us");
+  STCAT_LAUNCH(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)microseconds * 100, (int*)nullptr);
+  return launch_status();
+}
+
 int stcat_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                          float* bias, int C, float eps, void* stream) {
   if (C <= 0) return fail("frozen_bn_fold: C=%d", C);

@@ -28,6 +28,22 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+def init_rccl_process_group(device: torch.device, **kw) -> None:
+    """`dist.init_process_group("nccl")` (= RCCL on ROCm) with the collectives on a HIGH-PRIORITY stream: HIP keeps a
+    separate set of hardware queues per stream priority, so RCCL's stream never shares a queue (= serialises) with the
+    compute streams of the step, whose four normal-priority queues are then all ours (stcat_amd.ops._pick_streams), and
+    the all-reduce kernels are scheduled ahead of the backward kernels they overlap with."""
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except (AttributeError, TypeError):
+        pass
+    if opts is not None and not os.environ.get("STCAT_RCCL_NORMAL_PRIORITY"):
+        dist.init_process_group("nccl", device_id=device, pg_options=opts, **kw)
+    else:
+        dist.init_process_group("nccl", device_id=device, **kw)
+
+
 DEAD_PARAM_MARKERS = ("ground_encoder.fusion.", ".ca_qtime_proj.")
 
 

@@ -114,6 +114,88 @@ FORK_ENABLED = not os.environ.get("STCAT_NO_FORK")  # two-stream decoders (Query
 GRAD_SINK = None  # dist.GradBucketReducer when gradients are exchanged: .early(params, grads) takes them mid-backward
 
 
+STREAM_PROBE = not os.environ.get("STCAT_NO_STREAM_PROBE")
+_PICKED = {}          # device -> [side stream, weight-gradient stream, ...]
+PICK_REPORT = {}      # device -> what the probe saw (bench.py prints it)
+
+
+def _pick_streams(dev):
+    """Side streams that REALLY run beside the current stream.  HIP maps all streams of a process onto GPU_MAX_HW_QUEUES
+    (default 4) hardware queues per priority; two streams that share a queue serialise, and which ones share depends on
+    how many streams the framework / RCCL created before us (measured: with a live RCCL process group the second forward
+    chain landed on the main stream's queue — the backbone forward lost its overlap, +3.5 ms per C3 step; raising
+    GPU_MAX_HW_QUEUES instead made the step 25 % slower; profiles/r03_hw_queues.log).  So the choice is MEASURED once per
+    device: candidates from torch's stream pool are timed against the current stream and against each other with a
+    500 us one-workgroup spin kernel (stcat_spin), host-timed — concurrent pairs take ~0.5 ms, queue-sharing pairs ~1 ms — and the
+    first pairwise-concurrent triple (current, side, weight-gradient) is kept.  ~40 ms once, before the first step."""
+    got = _PICKED.get(dev)
+    if got is not None:
+        return got
+    cands = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    picked, report = cands[:2], {"probed": False}
+    main = torch.cuda.current_stream(dev)
+    if (STREAM_PROBE and L._backend == "hip" and dev.type == "cuda" and L.RECORDER is None
+            and not torch.cuda.is_current_stream_capturing()):
+        lib = L.load()
+        us = 500
+
+        import time
+
+        def run_ms(streams):
+            # host-timed, no cross-stream events: device idle -> launch on every stream -> device idle again (event waits
+            # between queues add ~0.2 ms of their own inside a busy process and blur the 1x / 2x answer)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for st in streams:
+                if lib.stcat_spin(us, st.cuda_stream) != 0:
+                    raise L.StcatHipError("stcat_spin failed")
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) * 1e3
+
+        def pair_ms(a, b):
+            return min(run_ms((a, b)), run_ms((a, b)))
+
+        def one_ms(a):
+            return run_ms((a,))
+
+        pair_ms(main, cands[0])                       # warm-up (first launch on a fresh stream)
+        one_ms(main)
+        single = min(one_ms(main), one_ms(main))      # the spin's real length (the counter's rate is not assumed)
+        conc = lambda a, b: pair_ms(a, b) < 1.5 * single   # noqa: E731
+        with_main = [pair_ms(main, c) for c in cands]
+        beside_main = [c for c, ms in zip(cands, with_main) if ms < 1.5 * single]
+        side = wg = None
+        for i, a in enumerate(beside_main):
+            for b in beside_main[i + 1:]:
+                if conc(a, b):
+                    side, wg = a, b
+                    break
+            if side is not None:
+                break
+        if side is None and beside_main:              # no concurrent pair: one stream for both roles still beats sharing
+            side = wg = beside_main[0]                # the main stream's queue
+        if side is not None:
+            picked = [side, wg]
+        report = {"probed": True, "candidates": len(cands), "concurrent_with_main": len(beside_main),
+                  "picked": [cands.index(side) if side is not None else None, cands.index(wg) if wg is not None else None],
+                  "spin_ms": round(single, 3), "pair_ms_with_main": [round(x, 3) for x in with_main]}
+    _PICKED[dev] = picked
+    PICK_REPORT[str(dev)] = report
+    return picked
+
+
+def side_stream(dev, index: int = 0):
+    """the package's side streams, by index: 0 serves the forward chains of the backbone AND the forked time decoder
+    (never busy together); 1 is the weight-gradient stream (WgradStream).  Main + side + weight-gradient (+ RCCL's) fit
+    the four hardware queues HIP gives a process by default; _pick_streams makes sure they really sit on different ones."""
+    if index < 2:
+        return _pick_streams(dev)[index]
+    have = _SIDE_STREAMS.setdefault(dev, [])
+    while len(have) <= index - 2:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[index - 2]
+
+
 def _wait_stream(waiter, signal) -> None:
     """waiter.wait_stream(signal); mirrored into the launch plan that is being recorded, if any"""
     waiter.wait_stream(signal)
@@ -140,9 +222,7 @@ class fork_stream:
         if self.active:
             dev = like.device
             self.main = torch.cuda.current_stream(dev)
-            self.side = _SIDE_STREAMS.get(dev)
-            if self.side is None:
-                self.side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            self.side = side_stream(dev, 0)
             self.ctx = torch.cuda.stream(self.side)
 
     def __enter__(self):
@@ -1333,7 +1413,7 @@ class WgradStream:
             self.main = torch.cuda.current_stream(dev)
             self.side = _WGRAD_STREAMS.get(dev)
             if self.side is None:
-                self.side = _WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                self.side = _WGRAD_STREAMS[dev] = side_stream(dev, 1)
             self.ctx = None
 
     def __enter__(self):

@@ -42,3 +42,42 @@ def test_no_cpu_fallback():
     from stcat_amd import ops
     with pytest.raises(L.StcatHipError):
         ops.linear(torch.zeros(4, 64), torch.zeros(64, 64), torch.zeros(64))
+
+
+@pytest.mark.gpu
+def test_gpu_side_streams_run_beside_the_current_stream():
+    """ops._pick_streams: the side stream (forward chains / forked decoder) and the weight-gradient stream it returns sit
+    on hardware queues of their own — two 500 us spin kernels on any two of (current, side, weight-gradient) finish in
+    well under 2 x 500 us.  (HIP maps streams onto 4 hardware queues; profiles/r03_hw_queues.log)"""
+    import time
+
+    import torch
+
+    from stcat_amd import ops
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L._lib = None
+    L._backend = "hip"
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    ops._PICKED.pop(dev, None)
+    side, wg = ops.side_stream(dev, 0), ops.side_stream(dev, 1)
+    rep = ops.PICK_REPORT[str(dev)]
+    assert rep["probed"] and rep["concurrent_with_main"] >= 2, rep
+    assert side is not wg
+    main = torch.cuda.current_stream(dev)
+
+    def run(streams):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for st in streams:
+            assert lib.stcat_spin(500, st.cuda_stream) == 0
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
+
+    one = min(run([main]) for _ in range(3))
+    for pair in ((main, side), (main, wg), (side, wg)):
+        both = min(run(pair) for _ in range(3))
+        assert both < 1.5 * one, (both, one, rep)
+    assert min(run((main, side, wg)) for _ in range(3)) < 1.5 * one
+    assert ops.WgradStream(torch.empty(1, device=dev)).side is wg

@@ -18,7 +18,7 @@ def main():
     rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
     # steps are delimited by the frame-stack stem kernel (one per forward)
     stems = [i for i, r in enumerate(rows) if "igemm_stem_kernel" in r[2]]
@@ -31,6 +31,8 @@ def main():
     wall = (t1 - t0) / 1e6
     HEAVY = 40_000  # ns
     ev = []
+    step_q = step
+    step = [(s, e, n) for s, e, n, _ in step]
     for s, e, n in step:
         heavy = (e - s) >= HEAVY
         ev.append((s, 1, heavy))
@@ -82,6 +84,20 @@ def main():
         a_[1] += e - s
     for k, (c, tns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print(f"    {tns/1e6:7.3f} ms {c:5d}x  {k}")
+    # hardware queues: HIP maps its streams onto GPU_MAX_HW_QUEUES (default 4) HSA queues; streams that share one serialise
+    qs = {}
+    for s, e, n, q in step_q:
+        a_ = qs.setdefault(q, [0, 0, s, e, {}])
+        a_[0] += 1
+        a_[1] += e - s
+        a_[2] = min(a_[2], s)
+        a_[3] = max(a_[3], e)
+        k = n.split("(")[0].replace("void ", "")[:28]
+        a_[4][k] = a_[4].get(k, 0) + (e - s)
+    print(f"  hardware queues used in the step: {len(qs)}")
+    for q, (c, tns, s0, e0, names) in sorted(qs.items(), key=lambda kv: -kv[1][1]):
+        top = ", ".join(f"{k} {v/1e6:.1f}" for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:4])
+        print(f"    queue {q}: {c:5d} launches, {tns/1e6:7.2f} ms of kernels, active {((s0 - t0)/1e6):6.2f} .. {((e0 - t0)/1e6):6.2f} ms | {top}")
     # library (at::native / rocPRIM) kernels by functor: what is still not ours
     import re
     lib = {}
