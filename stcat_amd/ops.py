@@ -127,7 +127,7 @@ def _pick_streams(dev):
     GPU_MAX_HW_QUEUES instead made the step 25 % slower; profiles/r03_hw_queues.log).  So the choice is MEASURED once per
     device: candidates from torch's stream pool are timed against the current stream and against each other with a
     500 us one-workgroup spin kernel (stcat_spin), host-timed — concurrent pairs take ~0.5 ms, queue-sharing pairs ~1 ms — and the
-    first pairwise-concurrent triple (current, side, weight-gradient) is kept.  ~40 ms once, before the first step."""
+    first (up to) three pairwise-concurrent ones are kept: [side, weight-gradient, spare].  ~40 ms once, before the first step."""
     got = _PICKED.get(dev)
     if got is not None:
         return got
@@ -164,21 +164,19 @@ def _pick_streams(dev):
         conc = lambda a, b: pair_ms(a, b) < 1.5 * single   # noqa: E731
         with_main = [pair_ms(main, c) for c in cands]
         beside_main = [c for c, ms in zip(cands, with_main) if ms < 1.5 * single]
-        side = wg = None
-        for i, a in enumerate(beside_main):
-            for b in beside_main[i + 1:]:
-                if conc(a, b):
-                    side, wg = a, b
-                    break
-            if side is not None:
+        chosen = []                                   # greedy: pairwise-concurrent streams beside the current one
+        for c in beside_main:
+            if len(chosen) == 3:
                 break
-        if side is None and beside_main:              # no concurrent pair: one stream for both roles still beats sharing
-            side = wg = beside_main[0]                # the main stream's queue
-        if side is not None:
-            picked = [side, wg]
+            if all(conc(c, o) for o in chosen):
+                chosen.append(c)
+        if chosen:
+            picked = list(chosen)
         report = {"probed": True, "candidates": len(cands), "concurrent_with_main": len(beside_main),
-                  "picked": [cands.index(side) if side is not None else None, cands.index(wg) if wg is not None else None],
-                  "spin_ms": round(single, 3), "pair_ms_with_main": [round(x, 3) for x in with_main]}
+                  "picked": [cands.index(c) for c in chosen], "spin_ms": round(single, 3),
+                  "pair_ms_with_main": [round(x, 3) for x in with_main]}
+    while len(picked) < 2:                            # (fewer than two queues beside the current one: roles share a stream)
+        picked.append(picked[-1])
     _PICKED[dev] = picked
     PICK_REPORT[str(dev)] = report
     return picked
@@ -188,12 +186,13 @@ def side_stream(dev, index: int = 0):
     """the package's side streams, by index: 0 serves the forward chains of the backbone AND the forked time decoder
     (never busy together); 1 is the weight-gradient stream (WgradStream).  Main + side + weight-gradient (+ RCCL's) fit
     the four hardware queues HIP gives a process by default; _pick_streams makes sure they really sit on different ones."""
-    if index < 2:
-        return _pick_streams(dev)[index]
-    have = _SIDE_STREAMS.setdefault(dev, [])
-    while len(have) <= index - 2:
+    got = _pick_streams(dev)
+    if index < len(got):
+        return got[index]
+    have = _SIDE_STREAMS.setdefault(dev, [])          # beyond the measured ones: may share a hardware queue
+    while len(have) <= index - len(got):
         have.append(torch.cuda.Stream(device=dev))
-    return have[index - 2]
+    return have[index - len(got)]
 
 
 def _wait_stream(waiter, signal) -> None:
