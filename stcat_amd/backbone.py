@@ -277,8 +277,17 @@ class _BackboneFnPl(Function):
                         ops.pl_conv_fwd_raw(*args, out=o)
             return yp, yf_
 
+        if sides:
+            # Everything the chains READ must be queued on the main stream before they fork off it: on the first call the
+            # FrozenBN folds (scale / bias per layer, cached afterwards) are launches of their own — folded inside the
+            # block loop below they ran on the main stream while the side chain already read them (a first-step race
+            # that a later warm step never shows; found by tests/test_dp_model.py once the stream probe moved the timing)
+            for _, blk in blocks:
+                blk.bn1.folded(), blk.bn2.folded(), blk.bn3.folded()
+                if blk.downsample is not None:
+                    blk.downsample[1].folded()
         for sd_ in sides:
-            ops._wait_stream(sd_, main)     # the other chains start behind the max-pool / the weight planes
+            ops._wait_stream(sd_, main)     # the other chains start behind the max-pool / the weight planes / the folds
         for bi, (li, blk) in enumerate(blocks):
             last = bi == len(blocks) - 1
             w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)

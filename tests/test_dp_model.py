@@ -64,7 +64,7 @@ def _worker(rank, world, port, q, use_plans=False):
     # single-process reference: both videos, no exchange
     red.close()
     red.deferred = True
-    ref = {}
+    ref, own = {}, {}
     for r in range(world):
         for p in model.parameters():
             p.grad = None
@@ -72,6 +72,8 @@ def _worker(rank, world, port, q, use_plans=False):
         for n, p in model.named_parameters():
             if p.grad is not None:
                 ref[n] = ref.get(n, 0) + p.grad.detach() / world
+                if r == rank:
+                    own[n] = p.grad.detach().clone()
     worst, worst_n = 0.0, ""
     assert set(got) == set(ref)
     errs = []
@@ -88,6 +90,16 @@ def _worker(rank, world, port, q, use_plans=False):
         errs.append((err, n))
         if err > worst:
             worst, worst_n = err, n
+    if os.environ.get("STCAT_DP_DEBUG"):
+        print(rank, "streams:", ops.PICK_REPORT, flush=True)
+        for n in ("vis_encoder.0.body.layer2.1.conv1.weight", "vis_encoder.0.body.layer4.2.conv3.weight", "temp_embed.layers.1.weight",
+                  "ground_encoder.spatial_temporal_encoder.spatial_layers.0.linear1.weight"):
+            if n in got:
+                g, o, rf = got[n].double(), own[n].double(), ref[n].double()
+                oth = 2 * rf - o
+                print(rank, n, "|got| %.3e |ref| %.3e  got-ref %.2e  got-own %.2e  got-own/2 %.2e  got-other/2 %.2e  got-other %.2e"
+                      % (g.norm(), rf.norm(), (g - rf).norm(), (g - o).norm(), (g - o / 2).norm(), (g - oth / 2).norm(),
+                         (g - oth).norm()), flush=True)
     if os.environ.get("STCAT_DP_DEBUG") and rank == 0:
         owner = {n: bi for bi, b in enumerate(red.buckets) for n, _ in b["params"]}
         for err, n in sorted(errs, reverse=True)[:25]:
