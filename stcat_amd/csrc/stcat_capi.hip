@@ -1346,6 +1346,7 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_layernorm_fwd),
     STCAT_PLAN_FN(stcat_layernorm_bwd),
     STCAT_PLAN_FN(stcat_ew),
+    STCAT_PLAN_FN(stcat_spin),
     STCAT_PLAN_FN(stcat_ew2d),
     STCAT_PLAN_FN(stcat_stg_loss_fwd),
     STCAT_PLAN_FN(stcat_stg_loss_bwd),
