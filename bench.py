@@ -562,6 +562,24 @@ def main():
         eval_path = {"value": round(1.0 / dt_e, 3), "unit": "videos/sec", "ms_per_video": round(1e3 * dt_e, 2),
                      "what": f"2-pass eval (2 x {T // 2} frames) + PostProcess + span union + linear_interp "
                              f"({len(boxes_e)} boxes out), no_grad, eval mode"}
+        # the same with decoder + heads replayed from a hipGraph (BASELINE configs[4]; STCATNet.capture_decoder)
+        try:
+            model.capture_decoder(True)
+            with torch.no_grad():
+                evaluate_video(model, post, videos, ["synthetic"], sizes, ids, interpolate=True)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    boxes_g, span_g = evaluate_video(model, post, videos, ["synthetic"], sizes, ids, interpolate=True)
+                fence()
+            dt_g = (time.perf_counter() - t1) / 5
+            eval_path["captured_decoder"] = {"value": round(1.0 / dt_g, 3), "ms_per_video": round(1e3 * dt_g, 2),
+                                             "same_span": span_g == span_e,
+                                             "graph_replays": model._graphed_decoder.replays}
+        except RuntimeError as e:       # (reported, never fatal for the bench line)
+            eval_path["captured_decoder"] = {"error": str(e)[:200]}
+        finally:
+            model.capture_decoder(False)
         model.train(was_training)
 
     # Input side: the boundary can also take the decoder's uint8 HWC frames; ToTensor + Normalize are

@@ -46,3 +46,69 @@ class GraphedStep:
     def replay(self) -> torch.Tensor:
         self.graph.replay()
         return self.output
+
+
+class GraphedDecoder:
+    """Decoder-scope hipGraph (BASELINE.json configs[4]; STCATNet.capture_decoder): `fn(*tensors) -> tuple of tensors`
+    — the template generator, the box decoder, the time decoder on its forked stream and the heads under no_grad —
+    captured once per input signature (shapes, dtypes, strides) and replayed with one hipGraphLaunch.
+
+    * inputs are copied into static buffers before a replay (memory + positions: 2 x [T,S',256] fp32, 50 MB at T = 128;
+      the masks and the two [CLS] tensors are a few KB); outputs are the graph's static tensors — valid until the next
+      call with the same signature, like a launch plan's;
+    * the capture follows two eager warm-up calls on a side stream (lazy caches: transposed weights, sine tables, the
+      measured stream placement of ops._pick_streams) — only launches are captured, never a cache fill;
+    * the step's zero arena (ops.enable_zero_arena) is out of reach during capture: an accumulator taken from it would
+      be zero when captured and stale at every replay, so the skinny Linear launches take their plain (non-accumulating)
+      form inside the graph;
+    * the forked time decoder is part of the graph: its stream is joined into the capturing stream before the capture
+      ends (ops.fork_stream)."""
+
+    MAX_GRAPHS = 4
+
+    def __init__(self, fn: Callable):
+        self.fn = fn
+        self.graphs = {}
+        self.replays = 0
+
+    @staticmethod
+    def _sig(args):
+        return tuple((tuple(a.shape), a.dtype, tuple(a.stride()), str(a.device)) if torch.is_tensor(a) else a for a in args)
+
+    def _capture(self, args):
+        from . import ops
+        dev = next(a.device for a in args if torch.is_tensor(a))
+        static_in = [a.clone() if torch.is_tensor(a) else a for a in args]
+        arena = ops._ARENA.pop(str(dev), None)
+        try:
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    self.fn(*static_in)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g):
+                static_out = self.fn(*static_in)
+        finally:
+            if arena is not None:
+                ops._ARENA[str(dev)] = arena
+        return g, static_in, static_out
+
+    def __call__(self, *args):
+        assert not torch.is_grad_enabled(), "the captured decoder is the inference path; training runs on launch plans"
+        key = self._sig(args)
+        got = self.graphs.get(key)
+        if got is None:
+            if len(self.graphs) >= self.MAX_GRAPHS:
+                self.graphs.pop(next(iter(self.graphs)))
+            got = self.graphs[key] = self._capture(args)
+        g, static_in, static_out = got
+        for s, a in zip(static_in, args):
+            if torch.is_tensor(s) and s.data_ptr() != a.data_ptr():
+                s.copy_(a)
+        g.replay()
+        self.replays += 1
+        return static_out

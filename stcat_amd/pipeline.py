@@ -57,22 +57,23 @@ class STCATNet(nn.Module):
         self.action_embed = MLP(hidden, hidden, 1, 2, dropout=0.3) if self.use_actioness else None
         self.ground_decoder.decoder.bbox_embed = self.bbox_embed                             # pipeline.py:50
 
-    def forward(self, videos: NestedTensor, texts, logger=None) -> Dict:
-        frames, frame_mask, durations = videos.decompose()
-        assert len(durations) == 1, "one video per rank (datasets/build.py:150-152)"
-        feat, mask, vis_pos = self.vis_encoder.forward_tokens(frames, frame_mask)            # pipeline.py:62
-        n, h, w, c = feat.shape
-        vis = ops.linear(feat.view(n * h * w, c), self.input_proj.weight.view(-1, c), self.input_proj.bias)  # :64
-        (text_mask, text_mem, _), text_cls = self.text_encoder(texts, frames.device)         # :69
-        memory, mem_mask, frames_cls, video_cls, mem_pos = self.ground_encoder.run(
-            vis.view(n, h * w, -1), mask.flatten(1), vis_pos, text_mask, text_mem)           # :72-74
-        hs, ref, time_hs, weights, _ = self.ground_decoder.run(memory.contiguous(), mem_mask, mem_pos,
-                                                               frames_cls, video_cls)       # :77-80
-        out = {"weights": weights[-1]}                                                       # :83-85
+    _graphed_decoder = None
+
+    def capture_decoder(self, on: bool = True) -> None:
+        """BASELINE.json configs[4] ("hipGraph-captured decoder"): under `torch.no_grad()` the template generator, the six
+        box-decoder layers with their anchor refinement and box head, the six time-decoder layers on the forked stream and
+        the span / actioness heads (query_decoder.py:13-147, 169-247, 310-438, 587-660; pipeline.py:77-103) — ~700
+        launches on [T,256] states, each shorter than its launch latency — are captured ONCE per input shape and replayed
+        with one hipGraphLaunch (stcat_amd/graph.py: GraphedDecoder).  Training steps are untouched (launch plans)."""
+        from .graph import GraphedDecoder
+        self._graphed_decoder = GraphedDecoder(self.decode) if on else None
+
+    def decode(self, memory, mem_mask, mem_pos, frames_cls, video_cls):
+        """pipeline.py:77-103 on tensors only: -> (coord [L,T,4], sted [L,1,T,2], act [L,1,T,1] | None, weights [L,1,T,T])"""
+        hs, ref, time_hs, weights, _ = self.ground_decoder.run(memory, mem_mask, mem_pos, frames_cls, video_cls)  # :77-80
         coord, self.ground_decoder.last_coord = getattr(self.ground_decoder, "last_coord", None), None
         if coord is None:
             coord = ops.sigmoid(ops.add(self.bbox_embed(hs), ops.inverse_sigmoid(ref)))      # [L,T,4]  :88-93
-        out["pred_boxes"] = coord[-1]
         act = None
         if composite.ENABLED:
             sted, act = composite.time_heads(self.temp_embed, self.action_embed if self.use_actioness else None, time_hs)
@@ -82,6 +83,24 @@ class STCATNet(nn.Module):
             sted = self.temp_embed(time_hs)[:, None]
             if self.use_actioness:
                 act = self.action_embed(time_hs)[:, None]
+        return coord, sted, act, weights
+
+    def forward(self, videos: NestedTensor, texts, logger=None) -> Dict:
+        frames, frame_mask, durations = videos.decompose()
+        assert len(durations) == 1, "one video per rank (datasets/build.py:150-152)"
+        feat, mask, vis_pos = self.vis_encoder.forward_tokens(frames, frame_mask)            # pipeline.py:62
+        n, h, w, c = feat.shape
+        vis = ops.linear(feat.view(n * h * w, c), self.input_proj.weight.view(-1, c), self.input_proj.bias)  # :64
+        (text_mask, text_mem, _), text_cls = self.text_encoder(texts, frames.device)         # :69
+        memory, mem_mask, frames_cls, video_cls, mem_pos = self.ground_encoder.run(
+            vis.view(n, h * w, -1), mask.flatten(1), vis_pos, text_mask, text_mem)           # :72-74
+        # decoder + heads: tensors in, tensors out — eager launches, or ONE hipGraph launch when capture_decoder() is on
+        dec = self.decode
+        if self._graphed_decoder is not None and not torch.is_grad_enabled():
+            dec = self._graphed_decoder
+        coord, sted, act, weights = dec(memory.contiguous(), mem_mask, mem_pos, frames_cls, video_cls)
+        out = {"weights": weights[-1]}                                                       # :83-85
+        out["pred_boxes"] = coord[-1]
         out["pred_sted"] = sted[-1]
         if act is not None:
             out["pred_actioness"] = act[-1]

@@ -42,16 +42,16 @@ def _clip_of(T, res, pad=None):
     return frames, mask, H, W
 
 
-def _run_hip(dev, T, res, L, with_backward=True, mma="f32", pad=None):
+def _run_hip(dev, T, res, L, with_backward=True, mma="f32", pad=None, graphed=False):
     from stcat_amd import _lib
     _lib.set_mma_mode(mma)
     try:
-        return _run_hip_impl(dev, T, res, L, with_backward, pad)
+        return _run_hip_impl(dev, T, res, L, with_backward, pad, graphed)
     finally:
         _lib.set_mma_mode("f32")
 
 
-def _run_hip_impl(dev, T, res, L, with_backward, pad=None):
+def _run_hip_impl(dev, T, res, L, with_backward, pad=None, graphed=False):
     text = synth.synth_text(L)
     model, criterion, wd = build_model(None, SyntheticText(text))
     model.eval()
@@ -59,7 +59,18 @@ def _run_hip_impl(dev, T, res, L, with_backward, pad=None):
     model.to(dev)
     frames, mask, H, W = _clip_of(T, res, pad)
     frames, mask = frames.to(dev), mask.to(dev)
-    out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
+    if graphed:
+        # decoder + heads through the hipGraph (STCATNet.capture_decoder, BASELINE configs[4]): captured on ANOTHER clip,
+        # then replayed on this one — what comes out is a replay fed through the static input buffers
+        assert not with_backward
+        model.capture_decoder(True)
+        with torch.no_grad():
+            other = synth.synth_frames(T, max(H, W), seed=77)[:, :, :H, :W].contiguous().to(dev)
+            model(NestedTensor(other, mask, [T]), ["synthetic"])
+            out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
+        assert model._graphed_decoder.replays == 2 and len(model._graphed_decoder.graphs) == 1
+    else:
+        out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
     keep = {k: v.detach().cpu().clone() for k, v in out.items() if torch.is_tensor(v)}
     keep["aux"] = [{k: v.detach().cpu().clone() for k, v in a.items()} for a in out["aux_outputs"]]
     sizes = torch.tensor([[float(H), float(W)]], device=dev).repeat(T, 1)
@@ -540,8 +551,27 @@ def test_gpu_c5_full_size_forward():
     forward + PostProcess in the bench arithmetic against the CPU oracle."""
     dev = use_hip()
     T, res, L = synth.CONFIGS["C5"]
-    _compare(_run_hip(dev, T, res, L, with_backward=False, mma=BENCH_MMA), _run_oracle(T, res, L, with_backward=False),
-             with_backward=False)
+    ref = _run_oracle(T, res, L, with_backward=False)
+    _compare(_run_hip(dev, T, res, L, with_backward=False, mma=BENCH_MMA), ref, with_backward=False)
+    # ... and as BASELINE configs[4] words it: with the decoder replayed from its hipGraph
+    _compare(_run_hip(dev, T, res, L, with_backward=False, mma=BENCH_MMA, graphed=True), ref, with_backward=False)
+
+
+@pytest.mark.gpu
+def test_gpu_captured_decoder_equals_eager():
+    """STCATNet.capture_decoder: the hipGraph replay of decoder + heads (fed through static input buffers, captured on a
+    different clip) gives the eager launches' outputs — square clip, and a padded non-square one (key-chunked one-query
+    attention, padding masks inside the captured region)"""
+    dev = use_hip()
+    for T, res, pad in ((8, 224, None), (4, (405, 720), "ragged")):
+        eager = _run_hip(dev, T, res, 10, with_backward=False, mma=BENCH_MMA, pad=pad)[0]
+        rep = _run_hip(dev, T, res, 10, with_backward=False, mma=BENCH_MMA, pad=pad, graphed=True)[0]
+        for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights", "post_boxes"):
+            close(rep[k], eager[k], 1e-6, f"captured decoder {k} (T={T}, {res})", absolute=True)
+        assert rep["post_sted"] == eager["post_sted"]
+        for a, b in zip(rep["aux"], eager["aux"]):
+            for k in a:
+                close(a[k], b[k], 1e-6, f"captured decoder aux {k}", absolute=True)
 
 
 @pytest.mark.gpu
