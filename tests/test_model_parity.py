@@ -567,11 +567,12 @@ def test_gpu_captured_decoder_equals_eager():
         eager = _run_hip(dev, T, res, 10, with_backward=False, mma=BENCH_MMA, pad=pad)[0]
         rep = _run_hip(dev, T, res, 10, with_backward=False, mma=BENCH_MMA, pad=pad, graphed=True)[0]
         for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights", "post_boxes"):
-            close(rep[k], eager[k], 1e-6, f"captured decoder {k} (T={T}, {res})", absolute=True)
+            # (not bitwise: the eager run goes through the training-form nodes, and split-K sums are added in arrival order)
+            close(rep[k], eager[k], 1e-5, f"captured decoder {k} (T={T}, {res})")
         assert rep["post_sted"] == eager["post_sted"]
         for a, b in zip(rep["aux"], eager["aux"]):
             for k in a:
-                close(a[k], b[k], 1e-6, f"captured decoder aux {k}", absolute=True)
+                close(a[k], b[k], 1e-5, f"captured decoder aux {k}")
 
 
 @pytest.mark.gpu
