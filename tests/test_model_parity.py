@@ -658,3 +658,60 @@ def test_gpu_two_pass_eval_path():
         # (two separate runs of the model: split-K launches add partial sums in arrival order, so the given frames
         # themselves agree to fp32 round-off, not bitwise)
         close(dense[(0, f)], torch.tensor(want[f][0], dtype=torch.float64), 2e-5, f"interpolated box {f}")
+
+
+def _trajectory(dev, mma, steps, T, res, L, lr):
+    """`steps` training steps (train mode: dropout on, the counter-based masks are the same function of (seed, counter)
+    in every arithmetic mode; clip 0.1 + AdamW through stcat_amd.optim, two alternating clips) -> the loss of every step"""
+    from stcat_amd import _lib, ops, optim
+    _lib.set_mma_mode(mma)
+    try:
+        model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
+        synth.fill_module_(model)
+        model.to(dev).train()
+        ops.manual_seed(5)
+        opt = optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=1e-4)
+        clips = []
+        for s in range(2):
+            act, tb = synth.synth_targets(T, seed=s)
+            clips.append((synth.synth_frames(T, res, seed=s).to(dev),
+                          [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}]))
+        mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+        losses = []
+        for s in range(steps):
+            frames, tgt = clips[s % 2]
+            opt.zero_grad()
+            out = model(NestedTensor(frames, mask, [T]), ["synthetic"])
+            l = criterion(out, tgt, [T])
+            total = sum(l[k] * wd[k] for k in l)
+            total.backward()
+            opt.step(max_grad_norm=0.1)
+            losses.append(total.item())
+        return losses
+    finally:
+        _lib.set_mma_mode("f32")
+
+
+@pytest.mark.gpu
+def test_gpu_loss_trajectory_of_the_modes():
+    """several optimizer steps, not one gradient.  Eight train-mode steps at C1 (T=8, 224 x 224) with
+    the fused clip + AdamW tail in the exact-fp32 mode, in the fp32-class default `bf16x6p` and in the 16-bit throughput
+    mode: the loss sequences stay together — fp32-class within 1e-3 relative at every step (run-to-run noise of the
+    exact mode itself: atomically ordered split-K sums, ReLU-kink flips, amplified by the optimizer), the throughput
+    mode within 1e-2 — and all of them go down."""
+    dev = use_hip()
+    T, res, L = synth.CONFIGS["C1"]
+    steps, lr = 8, 2e-5
+    ref = _trajectory(dev, "f32", steps, T, res, L, lr)
+    again = _trajectory(dev, "f32", steps, T, res, L, lr)
+    x6 = _trajectory(dev, BENCH_MMA, steps, T, res, L, lr)
+    x3 = _trajectory(dev, THROUGHPUT_MMA, steps, T, res, L, lr)
+    rel = lambda a, b: max(abs(p - q) / max(1.0, abs(q)) for p, q in zip(a, b))   # noqa: E731
+    noise = rel(again, ref)
+    print(f"loss trajectories: f32 {ref}\n  f32 again (noise {noise:.2e})\n  bf16x6p {x6} (dev {rel(x6, ref):.2e})\n"
+          f"  bf16x3p {x3} (dev {rel(x3, ref):.2e})")
+    assert all(map(lambda v: v == v and abs(v) < 1e6, ref + x6 + x3))
+    assert rel(x6, ref) <= max(1e-3, 3 * noise), (x6, ref)
+    assert rel(x3, ref) <= max(1e-2, 3 * noise), (x3, ref)
+    for tr in (ref, x6, x3):            # same clip, six optimizer steps later: the loss went down
+        assert tr[6] < tr[0] and tr[7] < tr[1], tr
