@@ -29,6 +29,26 @@ def test_bench_two_ranks_gloo():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_gloo_c3():
+    """the benchmark configuration ITSELF (C3: T=64, 448 x 448) under two ranks — both share the box's one
+    GPU over gloo, so the step time says nothing; what is checked is the N > 1 contract of the line: n_gpus = world size,
+    value = videos of ALL ranks per max-over-ranks step, weak scaling, the 327 MB exchange, an exposed-communication figure."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, STCAT_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-exact", "--no-optim", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["workload"].startswith("C3") and d["config"]["allreduce_bytes"] == 327341100
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-2 * d["value"]
+    assert d["exposed_comm_ms_per_step"] is not None and d["dtype"].startswith("f32-class")
+
+
+@pytest.mark.gpu
 def test_bench_rccl_path_single_rank_and_json_is_last_line():
     """STCAT_FORCE_COMM=1 drives the complete RCCL path (process group on the device, barriers, bucketed async
     all-reduce + wait + mean, the loss's box-count all-reduce) with one rank — what a 1-GPU box can check of the
