@@ -126,8 +126,9 @@ def _pick_streams(dev):
     chain landed on the main stream's queue — the backbone forward lost its overlap, +3.5 ms per C3 step; raising
     GPU_MAX_HW_QUEUES instead made the step 25 % slower; profiles/r03_hw_queues.log).  So the choice is MEASURED once per
     device: candidates from torch's stream pool are timed against the current stream and against each other with a
-    500 us one-workgroup spin kernel (stcat_spin), host-timed — concurrent pairs take ~0.5 ms, queue-sharing pairs ~1 ms — and the
-    first (up to) three pairwise-concurrent ones are kept: [side, weight-gradient, spare].  ~40 ms once, before the first step."""
+    500 us one-workgroup spin kernel (stcat_spin), host-timed — concurrent pairs take ~0.5 ms, queue-sharing pairs ~1 ms —
+    and the first (up to) three pairwise-concurrent ones are kept: [side, weight-gradient, spare].  ~40 ms once, on the
+    first eager call (never inside a plan recording or a graph capture)."""
     got = _PICKED.get(dev)
     if got is not None:
         return got
