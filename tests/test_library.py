@@ -60,7 +60,8 @@ def test_gpu_side_streams_run_beside_the_current_stream():
     L._backend = "hip"
     lib = L.load()
     dev = torch.device("cuda:0")
-    ops._PICKED.pop(dev, None)
+    ops._PICKED.pop(dev, None)          # measure afresh, whatever an earlier test of this process picked ...
+    ops._WGRAD_STREAMS.pop(dev, None)   # ... and let WgradStream take the new choice
     side, wg = ops.side_stream(dev, 0), ops.side_stream(dev, 1)
     rep = ops.PICK_REPORT[str(dev)]
     assert rep["probed"] and rep["concurrent_with_main"] >= 2, rep
