@@ -31,9 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from stcat_amd import _lib, ops, plans, synth  # noqa: E402
-from stcat_amd.dist import GradBucketReducer  # noqa: E402
-from stcat_amd.misc import BoxList, NestedTensor  # noqa: E402
-from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
+from stcat_amd.harness import TrainStep  # noqa: E402
+from stcat_amd.misc import NestedTensor  # noqa: E402
 
 PEAK_TFLOPS_F32_MFMA = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_TFLOPS_BF16_MFMA = 2500.0  # dense bf16 MFMA peak; a split-bf16 xN product costs N bf16 MFMA flops per flop
@@ -269,10 +268,19 @@ def main():
     ap.add_argument("--no-plans", action="store_true",
                     help="issue every launch from Python (round-2 behaviour) instead of replaying the composite nodes' "
                          "recorded launch plans with one C call each (stcat_amd/plans.py, csrc/launch_plan.h)")
+    ap.add_argument("--serial", action="store_true",
+                    help="run EVERY step on one stream (ops.single_stream: no forked decoder, no second forward chain, no "
+                         "weight-gradient stream) — the schedule whose rocprofv3 kernel stats are per-kernel isolated "
+                         "durations (profiles/*_kernel_stats_serial.csv); never the headline")
     ap.add_argument("--no-optim", action="store_true", help="skip the (untimed-in-metric) optimizer-tail timing")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing (N=1 only)")
     ap.add_argument("--roberta-dummy", action="store_true",
-                    help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB)")
+                    help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB); "
+                         "default at N > 1 (SURVEY.md §8d: the reference's DDP also reduces the RoBERTa gradients)")
+    ap.add_argument("--no-roberta-dummy", action="store_true", help="N > 1: exchange the hot path's 327 MB only")
+    ap.add_argument("--hoist-loss-plan", action="store_true",
+                    help="build the loss's target-only index tensors and run its 1-element box-count all-reduce once, "
+                         "outside the steps (round-3 behaviour); default: inside every timed step, as the reference does")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,46 +312,20 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    roberta_dummy = args.roberta_dummy or (world > 1 and not args.no_roberta_dummy)
     _lib.load()
     _lib.set_mma_mode(args.mma)
 
     T, res, L = synth.CONFIGS[args.config]
-    model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
-    if args.eval_mode:
-        model.eval()  # dropout off (parity mode); gradients flow
-    else:
-        model.train()  # the measured workload: dropout active (FrozenBN has no train-mode state)
-        ops.manual_seed(20260929, rank)
-    synth.fill_module_(model)
-    model.to(dev)
-    reducer = GradBucketReducer(model, extra_numel=124_645_632 if args.roberta_dummy else 0, force_comm=force_comm)
-    arena = ops.enable_zero_arena(dev, 120_000_000)  # weight-gradient accumulators etc.: one memset per step
-
-    frames = synth.synth_frames(T, res, seed=1000 * 3 + rank).to(dev)
-    mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
-    videos = NestedTensor(frames, mask, [T])
-    act, tb = synth.synth_targets(T, seed=rank)
-    targets = [{"actioness": act.to(dev), "boxs": BoxList(tb).to(dev)}]
-
-    # target-derived index/mask tensors belong to the input pipeline (they depend on the annotations only)
-    plan = criterion.plan(targets, [T], dev)
-    uniform_w = len({wd[k] for k in wd if k.startswith("loss_bbox")}) == 1  # aux copies share the main weights
-
-    plan.num_boxes(dev)  # the loss's 1-element box-count all-reduce happens here, once per batch
-
-    def compute():
-        """forward + loss + backward of one video: no collectives, no host syncs (capturable)"""
-        ops.dropout_begin_step(dev)
-        arena.reset()
-        # training updates the fp32 weights between steps, so the per-step split of all conv weights into bf16 planes
-        # (+ the transposed, FrozenBN-scaled copies for the data gradients) is part of every step: no optimizer runs
-        # inside the timed region, hence the epoch bump that makes the refresh launch run as it does in training
-        ops.WEIGHT_EPOCH += 1
-        out = model(videos, ["synthetic"])
-        losses = criterion(out, targets, [T], plan=plan)
-        total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
-        total.backward()
-        return total
+    # the step itself lives in stcat_amd/harness.py (tests/test_model_parity.py runs the same object against the
+    # reference's fixtures): model, criterion, bucketed reducer, zero arena, per-step loss plan
+    ts = TrainStep(dev, args.config, rank=rank, train=not args.eval_mode, roberta_dummy=roberta_dummy,
+                   force_comm=force_comm, loss_plan_inside=not (args.hoist_loss_plan or args.graph))   # (a capture cannot hold the plan's H2D copy)
+    model, criterion, wd, reducer, arena = ts.model, ts.criterion, ts.wd, ts.reducer, ts.arena
+    videos, mask, targets = ts.videos, ts.videos.mask, ts.targets
+    uniform_w = ts.uniform_w
+    compute = ts.compute
+    ts.loss_plan()
 
     comm = world > 1 or force_comm
     comm_events = []  # (end of backward, gradients averaged) per step: the EXPOSED part of the gradient exchange
@@ -384,6 +366,8 @@ def main():
             reducer.finish()
             return total
 
+    if args.serial:
+        ops.FORK_ENABLED = ops.WGRAD_STREAM_ENABLED = False
     use_plans = not args.no_plans and not args.graph
     plans.enable(use_plans)
     if use_plans:
@@ -416,22 +400,30 @@ def main():
         step = eager_step
     roof, kernels, gemm_shapes = None, None, None
     if not args.no_profile:
-        # one extra instrumented step; EVERY rank runs it (a step contains collectives), rank 0 records events.
-        # It brackets every launch with HIP events from Python, so it runs launch by launch (same kernels, same order)
+        # Two extra instrumented steps; EVERY rank runs them (a step contains collectives), rank 0 records events.  They
+        # bracket every launch with HIP events on the launch's own stream, launch by launch from Python (same kernels,
+        # same order as the replayed plans).  (1) the step as scheduled — three streams, kernels of different streams
+        # overlap, so a launch's duration there is a CO-SCHEDULED figure; (2) the same step on ONE stream
+        # (ops.single_stream): kernels run one at a time, a launch's duration is the kernel's own.  The roofline is
+        # priced on (2) (297 x 0.306 ms of the dominant kernel "inside" an 84.9 ms step).
         plans.enable(False)
         if rank == 0:
             with LaunchProfiler() as prof:
                 step()
+            with ops.single_stream():
+                step()                                   # (allocator / cache warm-up of the one-stream schedule)
+                with LaunchProfiler() as prof_iso:
+                    step()
         else:
             step()
+            with ops.single_stream():
+                step()
+                step()
         plans.enable(use_plans)
-    if rank == 0 and not args.no_profile:
-        agg = prof.summary()
-        kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                       "tflops": (round(v["flop"] / v["ms"] / 1e9, 2) if v["flop"] and v["ms"] else None)}
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+
+    def family(agg):
         # dominant KERNEL: in the split-bf16 modes the conv forward and the conv data gradient (pre-transposed
-        # weights) are the same device kernel, igemm_bs_fwd_kernel<128,128,NS> — price them together
+        # weights) are the same device kernel — price them together
         fam = dict(agg)
         if args.mma in ("bf16x3p", "bf16x6p") and "stcat_pl_conv_fwd" in agg and "stcat_pl_conv_dgrad" in agg:
             a, b = agg["stcat_pl_conv_fwd"], agg["stcat_pl_conv_dgrad"]
@@ -443,8 +435,20 @@ def main():
             fam = {k: v for k, v in agg.items() if k not in ("stcat_conv_fwd", "stcat_conv_dgrad")}
             fam["igemm_bs_fwd_kernel (stcat_conv_fwd + stcat_conv_dgrad)"] = {
                 "launches": a["launches"] + b["launches"], "ms": a["ms"] + b["ms"], "flop": a["flop"] + b["flop"]}
+        return fam
+
+    if rank == 0 and not args.no_profile:
+        agg = prof.summary()
+        agg_iso = prof_iso.summary()
+        kernels = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                       "isolated_ms": round(agg_iso[k]["ms"], 3) if k in agg_iso else None,
+                       "tflops": (round(v["flop"] / agg_iso[k]["ms"] / 1e9, 2)
+                                  if v["flop"] and k in agg_iso and agg_iso[k]["ms"] else None)}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        fam, fam_iso = family(agg), family(agg_iso)
         dom = max((k for k in fam if fam[k]["flop"] > 0), key=lambda k: fam[k]["ms"])
-        d = fam[dom]
+        d = fam_iso.get(dom, fam[dom])       # ISOLATED durations: one stream, one kernel at a time
+        d_co = fam[dom]
         ach = d["flop"] / d["launches"] / (d["ms"] / d["launches"] * 1e-3) / 1e12
         # `achieved` = ALGORITHMIC flops (2 x MAC of the contraction) / launch time and `frac` = that
         # over the peak of the pipe the kernel runs on.  A split-bf16 product issues 3 (6) bf16 MFMA flops per
@@ -456,6 +460,12 @@ def main():
                 "issued_tflops": round(ach * mult, 2), "issued_frac": round(ach * mult / peak, 4),
                 "mfma_flops_per_algorithmic_flop": mult,
                 "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "isolated_avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "co_scheduled_avg_launch_ms": round(d_co["ms"] / d_co["launches"], 4),
+                "duration_note": "achieved / frac use the ISOLATED per-launch duration (instrumented step on one stream: "
+                                 "kernels run one at a time); co_scheduled = the same launches inside the three-stream "
+                                 "step, where kernels of other streams share the CUs; rocprofv3 kernel stats of both "
+                                 "schedules: profiles/r04_bench_c3_kernel_stats_{serial,bf16x6p}.csv",
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
         tr = _pmc_traffic(dom, args.mma)
         # `traffic`: HBM bytes per launch of the dominant kernel family (PMC FETCH_SIZE / WRITE_SIZE passes, see the
@@ -463,12 +473,32 @@ def main():
         roof["traffic"] = int(tr["MB_per_launch"] * 1e6) if tr else None
         roof["traffic_detail"] = tr
         roof["mfma_util"] = _pmc_mfma_util(args.mma)
-        mm = sum(v["flop"] for v in agg.values())
-        mm_ms = sum(v["ms"] for v in agg.values() if v["flop"] > 0)
+        mm = sum(v["flop"] for v in agg_iso.values())
+        mm_ms = sum(v["ms"] for v in agg_iso.values() if v["flop"] > 0)
         roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
                                     "gflop_per_step": round(mm / 1e9, 1)}
-        gemm_shapes = prof.shape_table()
+        gemm_shapes = prof_iso.shape_table()
     if comm:
+        dist.barrier()
+
+    # report the gradient exchange two ways.  The headline at N > 1 carries the reference-sized message
+    # (hot path 327 MB + a 498 MB stand-in for the RoBERTa gradients the reference's DDP also reduces); the same steps
+    # with the hot path's own 327 MB only are timed beside it.
+    hot_only = None
+    if world > 1 and roberta_dummy:
+        reducer.skip_extra = True
+        step()
+        fence()
+        t1 = time.perf_counter()
+        n_hot = max(2, min(args.steps, 10))
+        for _ in range(n_hot):
+            step()
+        fence()
+        dt_h = torch.tensor([time.perf_counter() - t1], device=dev)
+        dist.all_reduce(dt_h, op=dist.ReduceOp.MAX)
+        hot_only = {"allreduce_bytes": reducer.message_bytes, "steps": n_hot, "ms_per_step": round(1e3 * dt_h.item() / n_hot, 2),
+                    "value": round(world * n_hot / dt_h.item(), 4)}
+        reducer.skip_extra = False
         dist.barrier()
 
     # The other arithmetic modes, timed on the same step beside the headline: the exact-fp32 mode is the
@@ -601,7 +631,7 @@ def main():
                 ops.dropout_begin_step(dev)
                 arena.reset()
                 out = model(NestedTensor(dev_frames, mask, [T]), ["synthetic"])
-                losses = criterion(out, targets, [T], plan=plan)
+                losses = criterion(out, targets, [T], plan=ts.loss_plan())
                 total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
                 total.backward()
                 reducer.finish()
@@ -626,7 +656,7 @@ def main():
                 ops.dropout_begin_step(dev)
                 arena.reset()
                 out = model(NestedTensor(dev_frames, mask, [T]), ["synthetic"])
-                losses = criterion(out, targets, [T], plan=plan)
+                losses = criterion(out, targets, [T], plan=ts.loss_plan())
                 total = criterion.weighted_total(wd) if uniform_w else sum(losses[k] * wd[k] for k in losses)
                 total.backward()
                 reducer.finish()
@@ -671,19 +701,27 @@ def main():
             "config": {"workload": f"{args.config}: VidSTG e2e_STCAT_R101 hot path, T={T} res={res} d=256 L={L}, "
                                    "fwd+loss+bwd, 1 video/GPU", "parallelism": f"dp{world}",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout 0.1/0.3 on)",
+                       "schedule": "ONE stream (--serial)" if args.serial else "three streams (forward chains / forked time "
+                                   "decoder, weight gradients)",
                        "launch": ("one hipGraph per step" if args.graph else
                                   "launch plans: one C call replays each composite node's recorded launch sequence "
                                   "(backbone fwd/bwd, encoder, box/time decoder, heads)" if use_plans else
                                   "eager (launch by launch from Python)"),
-                       "allreduce_bytes": reducer.message_bytes},
+                       "allreduce_bytes": reducer.message_bytes,
+                       "allreduce": ({"allreduce": "all-reduce per bucket (RCCL's algorithm choice)",
+                                      "rs_ag": "reduce-scatter + all-gather per bucket"}[reducer.collective]
+                                     + "; STCAT_DP_COLLECTIVE switches; no multi-GPU figure has been measured by the builder"),
+                       "loss_plan": ("built once outside the steps (--hoist-loss-plan / --graph)" if (args.hoist_loss_plan or args.graph) else
+                                     "rebuilt inside every timed step (target index tensors from host-side annotations, "
+                                     "one pinned H2D copy, the 1-element box-count all-reduce)")},
+            "hot_path_only_exchange": hot_only,
             "roofline": roof, "cpu_baseline": cpu, "exact_f32_mode": exact, "throughput_mode": throughput_mode,
             "other_modes": other_modes,
             "optimizer_tail": opt_tail, "eval_path": eval_path, "input_side": loader,
             "timed_region": "forward + VideoSTGLoss + backward (+ gradient exchange at N > 1), including the per-step "
-                            "split of all conv weights into bf16 planes (as after an optimizer step); the target-only index "
-                            "tensors of the loss (LossPlan) and its 1-element box-count all-reduce "
-                            "(criterion.py:175-178) are built once per batch OUTSIDE the timed step (they depend on "
-                            "the annotations only; the reference rebuilds them inside its loss every step)",
+                            "split of all conv weights into bf16 planes (as after an optimizer step), the loss's "
+                            "target-derived index tensors (LossPlan, criterion.py:160-192) and its 1-element box-count "
+                            "all-reduce (criterion.py:175-178) — all inside every timed step since round 4",
             "kernels": kernels,
             "gemm_shapes": gemm_shapes,
         }

@@ -35,6 +35,46 @@ SD = Dict[str, torch.Tensor]
 NHEAD = 8
 BLOCKS = (3, 4, 23, 3)
 
+# --------------------------------------------------------------------------
+# train mode: the reference's dropout sites
+# --------------------------------------------------------------------------
+# The functions below are the EVAL-mode arithmetic unless a `sites` object is installed with `dropout_sites(...)`.
+# Then every nn.Dropout / attention-probability dropout of the reference path (modal_encoder.py:212-221,237-240;
+# query_decoder.py:269,286-303,344,431-436,565-580,612,653-658; attention.py:381; net_utils.py:17-25 with
+# pipeline.py:42,47) calls it, in the reference's execution order per section:
+#     sites.elementwise(section, x, p) -> x'          nn.Dropout on a tensor
+#     sites.probs(section, kind, attn, p, N, nh) -> attn'   dropout on softmax probabilities [N*nh, L, S];
+#                                                            kind = "self" (L = S queries) | "q1" (one query per frame)
+# section in {"enc", "box", "time", "heads"}.  torch's Philox stream cannot be reproduced by another implementation, so a
+# parity test hands in the masks the HIP kernels drew (counter-based: csrc/stcat_rng.h) — "same arithmetic given the
+# same mask" (tests/test_model_parity.py::_check_train_mode_against_oracle).
+_SITES = None
+P_LAYER = 0.1          # cfg.MODEL.STCAT.DROPOUT (experiments/*.yaml)
+P_HEAD = 0.3           # pipeline.py:42,47
+
+
+class dropout_sites:
+    def __init__(self, sites):
+        self.sites = sites
+
+    def __enter__(self):
+        global _SITES
+        self.prev, _SITES = _SITES, self.sites
+        return self.sites
+
+    def __exit__(self, *exc):
+        global _SITES
+        _SITES = self.prev
+        return False
+
+
+def _drop(section: str, x: torch.Tensor, p: float) -> torch.Tensor:
+    return x if _SITES is None else _SITES.elementwise(section, x, p)
+
+
+def _drop_probs(section: str, kind: str, pr: torch.Tensor, p: float, N: int, nh: int) -> torch.Tensor:
+    return pr if _SITES is None else _SITES.probs(section, kind, pr, p, N, nh)
+
 
 # --------------------------------------------------------------------------
 # backbone: torchvision ResNet-101 v1.5 with FrozenBatchNorm2d
@@ -108,9 +148,10 @@ def _masked_softmax(scores: torch.Tensor, kpm: Optional[torch.Tensor], bsz: int,
     return scores.softmax(dim=-1)
 
 
-def torch_mha(sd: SD, p: str, q_in, k_in, v_in, kpm=None, nh: int = NHEAD):
-    """torch.nn.MultiheadAttention forward (packed in-proj, eval mode).
-    q_in [L,N,E], k_in/v_in [S,N,E]; returns (out [L,N,E], head-mean weights [N,L,S])."""
+def torch_mha(sd: SD, p: str, q_in, k_in, v_in, kpm=None, nh: int = NHEAD, section: str = "", kind: str = "self"):
+    """torch.nn.MultiheadAttention forward (packed in-proj).
+    q_in [L,N,E], k_in/v_in [S,N,E]; returns (out [L,N,E], head-mean weights [N,L,S]).  Train mode: the dropout acts
+    on the probabilities BEFORE both P·V and the head mean (F.multi_head_attention_forward)."""
     W, B = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
     E = q_in.shape[-1]
     q = F.linear(q_in, W[:E], B[:E])
@@ -123,12 +164,13 @@ def torch_mha(sd: SD, p: str, q_in, k_in, v_in, kpm=None, nh: int = NHEAD):
     k = k.contiguous().view(S, N * nh, hd).transpose(0, 1)
     v = v.contiguous().view(S, N * nh, hd).transpose(0, 1)
     pr = _masked_softmax(torch.bmm(q, k.transpose(1, 2)), kpm, N, nh)
+    pr = _drop_probs(section, kind, pr, P_LAYER, N, nh)
     o = torch.bmm(pr, v).transpose(0, 1).contiguous().view(L, N, E)
     o = F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
     return o, pr.view(N, nh, L, S).sum(dim=1) / nh
 
 
-def dab_mha(sd: SD, p: str, q, k, v, kpm, nh: int = NHEAD):
+def dab_mha(sd: SD, p: str, q, k, v, kpm, nh: int = NHEAD, section: str = "box"):
     """DAB-DETR MultiheadAttention without q/k/v projections, vdim != embed_dim —
     grounding_model/attention.py:184-393 (scale :283-285, bmm :359, mask :369-375,
     max-subtracted softmax :379-380, PV :383, out_proj :386)."""
@@ -140,6 +182,7 @@ def dab_mha(sd: SD, p: str, q, k, v, kpm, nh: int = NHEAD):
     kh = k.contiguous().view(S, N * nh, hd).transpose(0, 1)
     vh = v.contiguous().view(S, N * nh, vd).transpose(0, 1)
     pr = _masked_softmax(torch.bmm(qh, kh.transpose(1, 2)), kpm, N, nh)
+    pr = _drop_probs(section, "q1", pr, P_LAYER, N, nh)                       # attention.py:381
     o = torch.bmm(pr, vh).transpose(0, 1).contiguous().view(L, N, vd * nh)
     return F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
@@ -152,16 +195,20 @@ def lin(x, sd: SD, p: str):
     return F.linear(x, sd[p + "weight"], sd[p + "bias"])
 
 
-def ffn(x, sd: SD, p: str):
-    return lin(F.relu(lin(x, sd, p + "linear1.")), sd, p + "linear2.")
+def ffn(x, sd: SD, p: str, section: str = ""):
+    """linear2(dropout(relu(linear1 x)))  (modal_encoder.py:239, query_decoder.py:435, 657)"""
+    return lin(_drop(section, F.relu(lin(x, sd, p + "linear1.")), P_LAYER), sd, p + "linear2.")
 
 
-def mlp(x, sd: SD, p: str, n_layers: int):
-    """models/net_utils.py:7-26 (dropout off: eval mode)."""
+def mlp(x, sd: SD, p: str, n_layers: int, dropout: float = 0.0, section: str = "heads"):
+    """models/net_utils.py:7-26: with a dropout probability the MLP drops after EVERY layer, the last one included
+    (:24 `i < self.num_layers` is always true) — temp_embed / action_embed (pipeline.py:42,47: p = 0.3)."""
     for i in range(n_layers):
         x = lin(x, sd, f"{p}layers.{i}.")
         if i < n_layers - 1:
             x = F.relu(x)
+        if dropout:
+            x = _drop(section, x, dropout)
     return x
 
 
@@ -171,9 +218,9 @@ def mlp(x, sd: SD, p: str, n_layers: int):
 def encoder_layer(sd: SD, p: str, src, kpm, pos):
     """TransformerEncoderLayer.forward (post-norm) — modal_encoder.py:228-242."""
     qk = src + pos
-    a, _ = torch_mha(sd, p + "self_attn.", qk, qk, src, kpm)
-    src = layer_norm(src + a, sd, p + "norm1.")
-    return layer_norm(src + ffn(src, sd, p), sd, p + "norm2.")
+    a, _ = torch_mha(sd, p + "self_attn.", qk, qk, src, kpm, section="enc")
+    src = layer_norm(src + _drop("enc", a, P_LAYER), sd, p + "norm1.")                      # dropout1 :237
+    return layer_norm(src + _drop("enc", ffn(src, sd, p, "enc"), P_LAYER), sd, p + "norm2.")  # dropout2 :240
 
 
 def cross_modal_encoder(sd: SD, feat, vis_mask, vis_pos, text_mask, text_mem,
@@ -252,8 +299,8 @@ def box_decoder_layer(sd: SD, p: str, tgt, memory, mem_kpm, pos, query_pos, time
     k = lin(tgt, sd, p + "sa_kcontent_proj.") + lin(time_embed, sd, p + "sa_ktime_proj.") \
         + lin(query_pos, sd, p + "sa_kpos_proj.")
     v = lin(tgt, sd, p + "sa_v_proj.")
-    a, w = torch_mha(sd, p + "self_attn.", q, k, v, torch.zeros(1, T, dtype=torch.bool))   # :341
-    tgt = layer_norm(tgt + a, sd, p + "norm1.")
+    a, w = torch_mha(sd, p + "self_attn.", q, k, v, torch.zeros(1, T, dtype=torch.bool), section="box")   # :341
+    tgt = layer_norm(tgt + _drop("box", a, P_LAYER), sd, p + "norm1.")                     # dropout1 :344
 
     S, n, d = memory.shape
     qc = lin(tgt, sd, p + "ca_qcontent_proj.")
@@ -268,9 +315,9 @@ def box_decoder_layer(sd: SD, p: str, tgt, memory, mem_kpm, pos, query_pos, time
     qq = torch.cat([qc.view(T, 1, NHEAD, hd), qs], dim=3).view(T, 1, 2 * d)               # :373
     kk = torch.cat([kc.view(S, n, NHEAD, hd), kp.view(S, n, NHEAD, hd)], dim=3).view(S, n, 2 * d)  # :382
     q_cross = qq[:, 0, :][None]                                                            # [1,n,2d]  :387-398
-    a = dab_mha(sd, p + "cross_attn.", q_cross, kk, vv, mem_kpm)                           # :402-409
-    tgt = layer_norm(tgt + a.view(1, T, d).transpose(0, 1), sd, p + "norm3.")              # :419-432
-    tgt = layer_norm(tgt + ffn(tgt, sd, p), sd, p + "norm4.")
+    a = dab_mha(sd, p + "cross_attn.", q_cross, kk, vv, mem_kpm, section="box")            # :402-409
+    tgt = layer_norm(tgt + _drop("box", a.view(1, T, d).transpose(0, 1), P_LAYER), sd, p + "norm3.")   # :419-432
+    tgt = layer_norm(tgt + _drop("box", ffn(tgt, sd, p, "box"), P_LAYER), sd, p + "norm4.")            # :435-437
     return tgt, w
 
 
@@ -302,12 +349,12 @@ def time_decoder_layer(sd: SD, p: str, tgt, memory, mem_kpm, pos, query_pos, tim
     """TimeDecoderLayer.forward — query_decoder.py:587-660."""
     T, _, d = tgt.shape
     qk = tgt + (query_pos + time_pos)
-    a, w = torch_mha(sd, p + "self_attn.", qk, qk, tgt, torch.zeros(1, T, dtype=torch.bool))  # :604-610
-    tgt = layer_norm(tgt + a, sd, p + "norm1.")
+    a, w = torch_mha(sd, p + "self_attn.", qk, qk, tgt, torch.zeros(1, T, dtype=torch.bool), section="time")  # :604-610
+    tgt = layer_norm(tgt + _drop("time", a, P_LAYER), sd, p + "norm1.")                        # :612
     q_cross = (tgt + query_pos)[:, 0, :][None]                                                # :618-634
-    a, _ = torch_mha(sd, p + "cross_attn_image.", q_cross, memory + pos, memory, mem_kpm)      # :633-639
-    tgt = layer_norm(tgt + a.view(1, T, d).transpose(0, 1), sd, p + "norm3.")
-    tgt = layer_norm(tgt + ffn(tgt, sd, p), sd, p + "norm4.")
+    a, _ = torch_mha(sd, p + "cross_attn_image.", q_cross, memory + pos, memory, mem_kpm, section="time", kind="q1")  # :633-639
+    tgt = layer_norm(tgt + _drop("time", a.view(1, T, d).transpose(0, 1), P_LAYER), sd, p + "norm3.")   # :653
+    tgt = layer_norm(tgt + _drop("time", ffn(tgt, sd, p, "time"), P_LAYER), sd, p + "norm4.")           # :657-658
     return tgt, w
 
 
@@ -353,8 +400,9 @@ def stcat_forward(sd: SD, frames, frame_mask, text, return_stages: bool = False)
     memory, mask, frames_cls, videos_cls = cross_modal_encoder(sd, feat, m, vis_pos, text_mask, text_mem)
     hs, ref, time_hs, weights, pos_query = query_decoder(sd, memory, mask, frames_cls, videos_cls, vis_pos)
     coord = (mlp(hs, sd, "bbox_embed.", 3) + inverse_sigmoid(ref)).sigmoid().flatten(1, 2)   # :88-93
-    sted = mlp(time_hs, sd, "temp_embed.", 2)                                                # :98
-    act = mlp(time_hs, sd, "action_embed.", 2)                                               # :103
+    head_p = P_HEAD if _SITES is not None else 0.0
+    sted = mlp(time_hs, sd, "temp_embed.", 2, dropout=head_p)                                # :98
+    act = mlp(time_hs, sd, "action_embed.", 2, dropout=head_p)                               # :103
     out = {"pred_boxes": coord[-1], "pred_sted": sted[-1], "pred_actioness": act[-1], "weights": weights[-1]}
     out["aux_outputs"] = [
         {"pred_sted": sted[i], "pred_boxes": coord[i], "weights": weights[i], "pred_actioness": act[i]}

@@ -61,6 +61,10 @@ class FrozenBatchNorm2d(nn.Module):
         bufs = (self.weight, self.bias, self.running_mean, self.running_var)
         key = tuple((b.data_ptr(), b._version) for b in bufs)
         if self._cache is None or self._cache[0] != key:
+            if self._cache is not None:
+                # a RE-fold (load_state_dict / .to() after the first step): launch plans baked the old fold's address
+                from . import plans
+                plans.invalidate()
             self._cache = (key, ops.frozen_bn_fold(*bufs, eps=1e-5))
         return self._cache[1]
 
@@ -476,7 +480,7 @@ class PositionEmbeddingSine(nn.Module):
         return self.tokens(tensor_list.mask).view(n, h, w, 256).permute(0, 3, 1, 2)
 
 
-class Joiner(nn.Sequential):
+class Joiner(plans.InvalidatesPlans, nn.Sequential):
     """backbone.py:147-159."""
 
     def __init__(self, backbone: Backbone, position_embedding: PositionEmbeddingSine):

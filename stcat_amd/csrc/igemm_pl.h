@@ -57,6 +57,8 @@ struct PlParams {
   float* C2f;                           // second scaled output
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
   const float* wscale;                  // wgrad: optional per-row factor dW[m][:] *= wscale[m] (a FrozenBN scale folded out of dY)
+  int stagger;                          // fwd kernel: phase stagger of the first-round workgroups, in 10 ns ticks per quarter
+                                        // (0 = off); set by the launcher for many-round, epilogue-heavy launches
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
                                         // 2 = epilogue without global loads / stores
   IgemmGeom g;
@@ -204,6 +206,22 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   const int num_n = p.N / BN;
   const int v = stcat_xcd_remap(blockIdx.x, gridDim.x);
   const IgemmGeom g = p.g;
+#ifndef STCAT_EMU
+  if (p.stagger > 0 && blockIdx.x < 256u) {
+    // Phase stagger (round 4).  Every tile of a launch costs the same, so the 256 workgroups of the first round start
+    // together, run their K loops together (HBM nearly idle) and their epilogues together (HBM saturated) — and so does
+    // every later round: matrix time and HBM time ADD although they use different units of the chip.  Delaying the
+    // first-round workgroups by 0 / 1 / 2 / 3 quarters of a tile period (ids 8 apart share an XCD, so every XCD holds
+    // all four phases) makes some CUs compute while others stream; the order is then kept by the dispatcher, which
+    // hands out the next tile when a CU frees up.  One-time cost: 3/8 of a tile period per CU on average.
+    const int phase = (blockIdx.x >> 3) & 3;
+    if (phase) {
+      const long t0 = (long)wall_clock64(), ticks = (long)phase * p.stagger;
+      long tt = t0;
+      while (tt - t0 < ticks) { __builtin_amdgcn_s_sleep(8); tt = (long)wall_clock64(); }
+    }
+  }
+#endif
   // row space: plain = pixel index m; parity form = (class, index inside the class), whole tiles per class
   const int Mc = p.par ? p.M >> 2 : p.M;                    // rows per class
   const int tpc = (Mc + BM - 1) / BM;                       // tiles per class

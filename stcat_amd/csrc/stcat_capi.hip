@@ -394,7 +394,8 @@ int pick_pl_tile(int M, int N, int K) {
 
 int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   PlParams p = p_;
-  p.debug = g_pl_debug;
+  p.debug = g_pl_debug & 0xff;
+  p.stagger = (g_pl_debug & 8) ? (g_pl_debug >> 8) : 0;
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");

@@ -99,11 +99,28 @@ class GradBucketReducer:
                 self.buckets.append({"params": tail, "numel": tail_n, "late": False})
         if late:
             self.buckets.append({"params": late, "numel": sum(p.numel() for _, p in late), "late": True})
+        # Which collective moves a bucket (STCAT_DP_COLLECTIVE): "allreduce" (RCCL picks ring / tree / direct by size) or
+        # "rs_ag" = reduce-scatter + all-gather issued back to back on RCCL's stream — the explicit form of SURVEY.md §5's
+        # "all seven xGMI links" plan, so the first 8-GPU run can A/B the two (no scaling figure has been measured yet:
+        # an 8-GPU node is not ours to launch on).  gloo (the CPU tests) has no reduce_scatter_tensor: all-reduce there.
+        self.collective = os.environ.get("STCAT_DP_COLLECTIVE", "allreduce")
+        if self.collective not in ("allreduce", "rs_ag"):
+            raise ValueError(f"STCAT_DP_COLLECTIVE={self.collective!r}: expected allreduce or rs_ag")
+        if self.collective == "rs_ag" and not self.avg_in_collective:
+            self.collective = "allreduce"
         self._owner = {}
+        pad_to = 64 * max(self.world, 1)      # a flat bucket splits into `world` equal, 256-byte aligned shards
         for bi, b in enumerate(self.buckets):
             dev = b["params"][0][1].device
+            b["padded"] = -(-b["numel"] // pad_to) * pad_to
             # the flat communication buffer only exists when there is somebody to talk to
-            b["flat"] = torch.zeros(b["numel"], dtype=torch.float32, device=dev) if self.comm else None
+            b["flat"] = torch.zeros(b["padded"], dtype=torch.float32, device=dev) if self.comm else None
+            b["shard"] = (torch.empty(b["padded"] // self.world, dtype=torch.float32, device=dev)
+                          if (self.comm and self.collective == "rs_ag") else None)
+            # the reference's DDP also reduces the text encoder's 124.6 M gradients, which are complete right after the
+            # encoder's backward — BEFORE the backbone's: the dummy message standing in for them is
+            # launched behind the bucket that holds input_proj (the first thing after the encoder), not in finish()
+            b["triggers_extra"] = any(n == "input_proj.weight" for n, _ in b["params"])
             b["views"] = []
             off = 0
             for n, p in b["params"]:
@@ -118,9 +135,13 @@ class GradBucketReducer:
             b["pending"] = len(b["params"])
             b["work"] = None
         dev0 = self.buckets[0]["params"][0][1].device
-        self.extra = torch.zeros(extra_numel, dtype=torch.float32, device=dev0) if (extra_numel and self.comm) else None
+        extra_padded = -(-extra_numel // pad_to) * pad_to
+        self.extra = torch.zeros(extra_padded, dtype=torch.float32, device=dev0) if (extra_numel and self.comm) else None
+        self._extra_shard = (torch.empty(extra_padded // self.world, dtype=torch.float32, device=dev0)
+                             if (self.extra is not None and self.collective == "rs_ag") else None)
         self._extra_work = None
         self.extra_numel = extra_numel
+        self.skip_extra = False      # True: leave the dummy (text-encoder-sized) message out of the following steps
         self.deferred = False  # True: hooks do nothing, finish() reduces the (static) gradient tensors afterwards
         self._view_of = {}
         for b in self.buckets:
@@ -140,6 +161,7 @@ class GradBucketReducer:
         for p in self.params:
             p.grad = None
         self._early.clear()
+        self._extra_work = None
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["work"] = None
@@ -185,8 +207,9 @@ class GradBucketReducer:
                     raise RuntimeError("GradBucketReducer.early: a bucket was already all-reduced when a second gradient "
                                        "for one of its parameters arrived; call finish() between backward passes or "
                                        "run gradient accumulation with STCAT_REDUCER_NO_OVERLAP=1")
-                again_s.append(g)
-                again_d.append(self._view_of[p])
+                if g.data_ptr() != self._view_of[p].data_ptr():   # (written through: the kernel accumulated in place)
+                    again_s.append(g)
+                    again_d.append(self._view_of[p])
                 continue
             if g.data_ptr() != self._view_of[p].data_ptr():      # (written through: already in the bucket)
                 srcs.append(g)
@@ -232,15 +255,35 @@ class GradBucketReducer:
                     v.zero_()
             if srcs:
                 torch._foreach_copy_(dsts, srcs)
-            op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
-            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+            b["work"] = self._reduce(b["flat"], b["shard"])
+            if b["triggers_extra"] and self.extra is not None and self._extra_work is None and not self.skip_extra:
+                self._extra_work = self._reduce(self.extra, self._extra_shard)
         b["pending"] = -1
+
+    def _reduce(self, flat, shard):
+        """asynchronous mean (RCCL) / sum (gloo) of one flat buffer over the ranks, in place"""
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+        if shard is not None:
+            dist.reduce_scatter_tensor(shard, flat, op=op, group=self.group, async_op=True)
+            return dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True)   # same stream: ordered
+        return dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         # (the post-accumulate hook also fires for a parameter whose node returned None because it was handed over through
         # early(): that one is counted already — counting it again would complete mixed buckets too soon and leave the
         # late bucket below zero, never reduced)
-        if self.deferred or p in self._early:
+        if self.deferred:
+            return
+        if p in self._early:
+            # handed over through early().  If autograd ALSO accumulated a gradient for it (the parameter is used outside
+            # the delivering node as well), that contribution must not be lost: add it into the bucket while that is still
+            # possible (ADVICE r03)
+            g, v = p.grad, self._view_of[p]
+            if g is not None and g.data_ptr() != v.data_ptr():
+                if self.buckets[self._owner[p]]["pending"] < 0:
+                    raise RuntimeError("GradBucketReducer: a parameter delivered through early() received a further "
+                                       "gradient from autograd after its bucket was all-reduced")
+                v.add_(g)
             return
         b = self.buckets[self._owner[p]]
         b["pending"] -= 1
@@ -252,11 +295,11 @@ class GradBucketReducer:
         parameter's .grad is (a view of) the averaged gradient."""
         if not self.comm:
             return
-        if self.extra is not None:
-            self._extra_work = dist.all_reduce(self.extra, group=self.group, async_op=True)
         for b in self.buckets:
             if self.deferred or b["pending"] >= 0:  # (eager) a parameter got no gradient: reduce what is there
                 self._launch(b)
+        if self.extra is not None and self._extra_work is None and not self.skip_extra:   # (no bucket triggered it)
+            self._extra_work = self._reduce(self.extra, self._extra_shard)
         for b in self.buckets:
             b["work"].wait()
             if not self.avg_in_collective and self.world > 1:
@@ -268,4 +311,4 @@ class GradBucketReducer:
 
     @property
     def message_bytes(self) -> int:
-        return 4 * (sum(b["numel"] for b in self.buckets) + self.extra_numel)
+        return 4 * (sum(b["numel"] for b in self.buckets) + (0 if self.skip_extra else self.extra_numel))

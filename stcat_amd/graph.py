@@ -29,19 +29,25 @@ class GraphedStep:
         # Round 3 replaced this path by launch plans (stcat_amd/plans.py); its newer multi-stream schedules — the two
         # forward chains of the backbone, the deferred weight gradients of the grounding model — record allocator
         # stream uses that a capture cannot carry, so a captured step runs the round-2 schedule.
+        # The two globals are scoped to warm-up + capture and restored afterwards (they used to stay set for
+        # the rest of the process, so every later eager step silently ran the round-2 schedule).
         from . import backbone, composite
+        saved = (backbone.FORWARD_CHAINS, composite.DEFER_WGRADS)
         backbone.FORWARD_CHAINS = 1
         composite.DEFER_WGRADS = False
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                step_fn()
-        torch.cuda.current_stream(device).wait_stream(side)
-        torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.output = step_fn()
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    step_fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.output = step_fn()
+        finally:
+            backbone.FORWARD_CHAINS, composite.DEFER_WGRADS = saved
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()

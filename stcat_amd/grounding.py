@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import composite, ops
+from . import composite, ops, plans
 from .misc import NestedTensor
 
 D_MODEL = 256
@@ -156,7 +156,7 @@ class SpatialTemporalEncoder(nn.Module):
         return x[:, 1:, :], x[:, 0, :], video
 
 
-class CrossModalEncoder(nn.Module):
+class CrossModalEncoder(plans.InvalidatesPlans, nn.Module):
     """modal_encoder.py:11-101."""
 
     def __init__(self, cfg=None):
@@ -415,7 +415,7 @@ class TimeDecoder(nn.Module):
         return torch.stack(inter), torch.stack(ws)
 
 
-class QueryDecoder(nn.Module):
+class QueryDecoder(plans.InvalidatesPlans, nn.Module):
     """query_decoder.py:13-147."""
 
     def __init__(self, cfg=None):

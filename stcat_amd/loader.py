@@ -38,6 +38,11 @@ class DeviceFramePrefetcher:
         i = self.k & 1
         if self.bufs[i] is None or self.bufs[i].shape != clip.shape or self.bufs[i].dtype != clip.dtype:
             self.bufs[i] = torch.empty(clip.shape, dtype=clip.dtype, device=self.dev)
+            # allocated on the CURRENT stream, first written on the copy stream: the block may have served kernels still
+            # queued on the current stream, so the copy stream waits for them, and the allocator is told
+            # about the second stream
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))
+            self.bufs[i].record_stream(self.copy_stream)
         src = clip
         if not clip.is_pinned():
             if self.stage[i] is None or self.stage[i].shape != clip.shape or self.stage[i].dtype != clip.dtype:

@@ -676,6 +676,7 @@ class _DropoutStream:
         self._base = {}    # device -> int64 [1 + SLOTS]: word 0 = master counter, words 1.. = the slots the kernels read
         self._slot = {}    # device -> index of the current slot
         self.pending = False   # a train-mode forward ran and its backward has not finished yet
+        self.trace = None      # debug / tests: a list that receives (host offset, decisions) of every site of the step
 
     def _default_seed(self) -> int:
         """Drop-in mode never calls manual_seed: the reference seeds torch with 42 + rank (scripts/train_net.py:296),
@@ -707,6 +708,8 @@ class _DropoutStream:
             self.seed = self._default_seed()
         off = self.offset
         self.offset = off + ((numel + 3) // 4) * 4
+        if self.trace is not None:
+            self.trace.append((off, int(numel)))
         if self.offset > self.STEP_SPAN:
             raise RuntimeError("dropout counter range of one step exhausted (2^36 decisions in one forward pass)")
         return self.seed, off, self.base(device).data_ptr()
@@ -773,6 +776,14 @@ def dropout_backward_done() -> None:
     _dropout_stream.pending = False
     if L.RECORDER is not None:
         L.RECORDER.effect(dropout_backward_done)
+
+
+def dropout_trace(on: bool = True):
+    """Test / debug aid: start (and return) the list of (host offset, decisions) pairs every dropout site appends to as it
+    takes its counter range, in launch order — with `dropout_keep_mask(seed, base + offset, n, p)` a host program can
+    rebuild the mask of every site of a step (tests/test_model_parity.py feeds them to the CPU oracle)."""
+    _dropout_stream.trace = [] if on else None
+    return _dropout_stream.trace
 
 
 def dropout_stream_state():
@@ -1091,6 +1102,9 @@ class WeightTransposer:
         import numpy as np
         key = tuple(w.data_ptr() for w in weights)
         if key != self.key:
+            if self.key is not None:      # a weight moved: launch plans hold the old table / the old raw pointers
+                from . import plans
+                plans.invalidate()
             dt = np.dtype([("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
                            ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4")])
             assert dt.itemsize == L.load().stcat_weight_transpose_entry_bytes()
@@ -1361,10 +1375,15 @@ class WeightPlanes:
         folded into the TRANSPOSED planes; returns ({ptr: Planes fwd}, {ptr: Planes transposed})"""
         import numpy as np
         tscales = tscales if tscales is not None else [None] * len(weights)
-        key = (tuple(w.data_ptr() for w in weights), bool(transposed) or bool(self.tr),
-               tuple(0 if t is None else t.data_ptr() for t in tscales))
+        # (the plane count is part of the key — ADVICE r03: switching bf16x3p -> bf16x6p on a live model must not reuse the
+        # two-plane buffers, the three-plane kernels would write / read a third plane past their end)
+        want_tr = bool(transposed) or bool(self.tr)
+        key = (tuple(w.data_ptr() for w in weights), want_tr,
+               tuple(0 if t is None else t.data_ptr() for t in tscales), L.plane_count())
         if key != self.key:
-            want_tr = key[1]
+            if self.key is not None:      # a weight moved / the plane mode changed: launch plans hold the old table
+                from . import plans
+                plans.invalidate()
             dt = np.dtype([("w", "<u8"), ("wh", "<u8"), ("wl", "<u8"), ("th", "<u8"), ("tl", "<u8"), ("tscale", "<u8"),
                            ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"), ("blk0", "<i4"), ("nbx", "<i4"),
                            ("nby", "<i4"), ("pad", "<i4"), ("pad2", "<i4")])
@@ -1392,6 +1411,8 @@ class WeightPlanes:
         # step that moved the fp32 weights — ADVICE r02)
         capturing = (weights[0].is_cuda and torch.cuda.is_current_stream_capturing()) or L.RECORDER is not None
         if state != self.state or capturing:
+            np_ = L.plane_count()
+            assert all(p.t.shape[0] == np_ for p in self.fwd.values()) and all(p.t.shape[0] == np_ for p in self.tr.values())
             L.call("stcat_weight_planes_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
             self.state = state
         return self.fwd, self.tr
@@ -1399,6 +1420,24 @@ class WeightPlanes:
 
 _WGRAD_STREAMS = {}
 WGRAD_STREAM_ENABLED = not os.environ.get("STCAT_NO_WGRAD_STREAM")
+
+
+class single_stream:
+    """`with ops.single_stream():` — every launch of the step on the caller's stream (no forked decoder, no second
+    forward chain, no weight-gradient stream): kernels run one at a time, so a per-launch duration measured inside is
+    the kernel's ISOLATED duration (bench.py's serialised instrumented step).  Launch plans carry both
+    switches in their signature, so eager / recorded steps inside and outside the block never share a plan."""
+
+    def __enter__(self):
+        global FORK_ENABLED, WGRAD_STREAM_ENABLED
+        self.saved = (FORK_ENABLED, WGRAD_STREAM_ENABLED)
+        FORK_ENABLED = WGRAD_STREAM_ENABLED = False
+        return self
+
+    def __exit__(self, *exc):
+        global FORK_ENABLED, WGRAD_STREAM_ENABLED
+        FORK_ENABLED, WGRAD_STREAM_ENABLED = self.saved
+        return False
 
 
 class WgradStream:

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import composite, ops
+from . import composite, ops, plans
 from .backbone import build_vis_encoder
 from .grounding import MLP, build_decoder, build_encoder
 from .misc import NestedTensor
@@ -37,7 +37,7 @@ class SyntheticText(nn.Module):
         return (self.mask, self.mem, None), self.cls
 
 
-class STCATNet(nn.Module):
+class STCATNet(plans.InvalidatesPlans, nn.Module):
     def __init__(self, cfg=None, text_encoder: Optional[nn.Module] = None):
         super().__init__()
         self.use_attn = True if cfg is None else cfg.SOLVER.USE_ATTN
@@ -136,11 +136,10 @@ class LossPlan:
         self.T, self.b = T, b
         bounds, rows = [], []
         for i, tgt in enumerate(targets):
-            on = torch.where(tgt["actioness"].cpu())[0].tolist()
-            bounds.append((on[0], on[-1]))
+            on = torch.where(tgt["actioness"].cpu())[0].tolist()     # (host-side annotations: no sync; the reference
+            bounds.append((on[0], on[-1]))                            #  syncs on the device copy here, criterion.py:163)
             rows.extend(range(i * T + on[0], i * T + on[-1] + 1))
         self.bounds = bounds
-        self.rows = torch.tensor(rows, dtype=torch.long).to(device, non_blocking=True)
         self.num_boxes_local = float(sum(len(t["boxs"]) for t in targets))
         self._num_boxes = None
         time_mask = torch.zeros(b, T, dtype=torch.bool)
@@ -157,17 +156,47 @@ class LossPlan:
             d_ = (-((grid - tgt_idx[:, None]) ** 2) / (2 * sigma ** 2)).exp()
             dists.append(F.normalize(d_ + 1e-6, p=1, dim=1))
         pos_or_pad = positive | (~time_mask)
-        self.time_mask = time_mask.to(device)
-        self.time_mask_f = time_mask.float().to(device)
-        self.pos_or_pad = pos_or_pad.to(device)
-        self.time_mask_u8 = time_mask.to(torch.uint8).to(device)
-        self.pos_or_pad_u8 = pos_or_pad.to(torch.uint8).to(device)
-        self.nb_neg = ((~pos_or_pad).sum(1) + 1e-6).float().to(device)
-        self.act_weight = weight.float().contiguous().to(device)
-        self.dist = torch.stack(dists, dim=-1).float().contiguous().to(device)  # [b,T,2]
-        self.tgt_boxes = torch.cat([t["boxs"].bbox for t in targets], dim=0).float().contiguous().to(device)
-        self.actioness = torch.stack([t["actioness"] for t in targets]).float().contiguous().to(device)
+        # every device tensor of the plan travels in ONE asynchronous copy from one pinned staging buffer (round 4: the
+        # plan is rebuilt inside every training step, as the reference rebuilds it inside its loss; ten pageable copies
+        # would each stall the host until the stream drained)
+        host = {
+            "rows": torch.tensor(rows, dtype=torch.long),
+            "tgt_boxes": torch.cat([t["boxs"].bbox.cpu() for t in targets], dim=0).float().contiguous(),
+            "dist": torch.stack(dists, dim=-1).float().contiguous(),                    # [b,T,2]
+            "nb_neg": ((~pos_or_pad).sum(1) + 1e-6).float(),
+            "act_weight": weight.float().contiguous(),
+            "actioness": torch.stack([t["actioness"].cpu() for t in targets]).float().contiguous(),
+            "time_mask_u8": time_mask.to(torch.uint8),
+            "pos_or_pad_u8": pos_or_pad.to(torch.uint8),
+        }
+        offs, total = {}, 0
+        for k, v in host.items():
+            offs[k] = total
+            total += (v.numel() * v.element_size() + 15) & ~15
+        cuda = torch.device(device).type == "cuda"
+        stage = torch.empty(total, dtype=torch.uint8, pin_memory=cuda)
+        for k, v in host.items():
+            n = v.numel() * v.element_size()
+            stage[offs[k]:offs[k] + n] = v.reshape(-1).view(torch.uint8)
+        buf = stage.to(device, non_blocking=True) if cuda else stage
+        self._buf = buf
+        for k, v in host.items():
+            n = v.numel() * v.element_size()
+            setattr(self, k, buf[offs[k]:offs[k] + n].view(v.dtype).view(v.shape))
         self.row_range = (rows[0], rows[-1] + 1) if rows == list(range(rows[0], rows[-1] + 1)) else None
+
+    # (bool / float forms of the masks, for callers that want them: views of the same buffer's contents)
+    @property
+    def time_mask(self):
+        return self.time_mask_u8.bool()
+
+    @property
+    def time_mask_f(self):
+        return self.time_mask_u8.float()
+
+    @property
+    def pos_or_pad(self):
+        return self.pos_or_pad_u8.bool()
 
     def num_boxes(self, dev):
         """criterion.py:175-178: box count averaged over ranks, clamped to >= 1.  It depends on the targets only,

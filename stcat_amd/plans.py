@@ -64,6 +64,22 @@ def clear() -> None:
 _CACHES: List[list] = []
 
 
+class InvalidatesPlans:
+    """nn.Module mixin of the seam modules (vision encoder, cross-modal encoder, query decoder, STCATNet): whatever moves
+    or rewrites their parameters / buffers behind a plan's back — `.to()` / `.cuda()` / `.double()` (nn.Module._apply),
+    `load_state_dict` (in-place copies: same pointers, new FrozenBN statistics) — bumps STATIC_EPOCH, so no recorded
+    plan matches any more and the next steps run eager -> record -> replay again (nothing ever called
+    invalidate(); replays skip FrozenBatchNorm2d.folded() and the weight-table key checks)."""
+
+    def _apply(self, fn, *a, **k):
+        invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        invalidate()
+        return super().load_state_dict(*a, **k)
+
+
 def _extent_bytes(t: torch.Tensor) -> int:
     if t.numel() == 0:
         return 0
@@ -337,7 +353,7 @@ class _ShimCtx:
 
 class _Entry:
     __slots__ = ("calls", "fwd", "bwd", "ctx", "outs", "pool", "live", "done", "single", "params", "grad_ptrs", "gsig",
-                 "spec", "param_pos")
+                 "spec", "param_pos", "refused", "param_ptrs")
 
     def __init__(self):
         self.calls = 0
@@ -352,6 +368,8 @@ class _Entry:
         self.params = None
         self.param_pos = None
         self.grad_ptrs = set()
+        self.param_ptrs = ()
+        self.refused = False     # a recording of this node ran kernels that are not ours: stays eager
 
 
 def _is_param(t) -> bool:
@@ -400,7 +418,9 @@ def _record(dev, ext, pool, body):
     """run body() with every launch mirrored into a new plan; returns (result, Plan)"""
     rec = Recorder(dev, ext)
     cuda = dev.type == "cuda"
-    watch = _Watch(rec, keepalive=(not cuda) or KEEPALL) if (STRICT or KEEPALL or not cuda) else None
+    # The dispatch watch is on for EVERY recording (one pass per plan): an aten kernel inside the node body (a
+    # .contiguous() of a strided input, an expand-sum) would run now and be missing from every replay (ADVICE r03)
+    watch = _Watch(rec, keepalive=(not cuda) or KEEPALL)
     prev = L.RECORDER
     L.RECORDER = rec
     try:
@@ -417,10 +437,27 @@ def _record(dev, ext, pool, body):
     finally:
         L.RECORDER = prev
     plan = rec.finalize()
-    if rec.foreign and STRICT:
-        raise L.StcatHipError(f"launch plan: the recorded region ran kernels that are not ours: {sorted(set(rec.foreign))}")
+    if rec.foreign:
+        if STRICT:
+            raise L.StcatHipError(f"launch plan: the recorded region ran kernels that are not ours: {sorted(set(rec.foreign))}")
+        # not replayable: the caller keeps the results of this pass (every launch did execute) and stays eager
+        STATS["refused"] = STATS.get("refused", 0) + 1
+        _warn_foreign(sorted(set(rec.foreign)))
+        return res, None
     STATS["recorded"] += 1
     return res, plan
+
+
+_WARNED = set()
+
+
+def _warn_foreign(names) -> None:
+    key = tuple(names)
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(f"stcat_amd launch plan refused (the node body ran kernels that are not ours: {list(names)}); "
+                      "this node stays on the eager path")
 
 
 class PlannedFn(Function):
@@ -454,8 +491,15 @@ class PlannedFn(Function):
         e.calls += 1
         ctx.node = node
         ctx.entry = None
+        if e.fwd is not None and e.param_ptrs != tuple(p.data_ptr() for p in e.params):
+            # a parameter's storage was swapped behind the plan (p.data = ..., an optimizer that replaces tensors): the
+            # per-module tables the plan points at (weight planes) hold the old address — start over
+            invalidate()
+            cache.remove(e)
+            e = _Entry()
+            e.gsig, e.spec, e.calls = None, None, 1
         busy = not e.done and e.live is not None and e.live() is not None
-        if e.calls <= WARMUP_CALLS or busy or not any(nig):
+        if e.calls <= WARMUP_CALLS or busy or not any(nig) or e.refused:
             STATS["eager"] += 1
             c = ctx.shim = _ShimCtx(nig)          # (the node indexes needs_input_grad by ITS argument positions)
             outs = node.forward(c, *args)
@@ -474,11 +518,19 @@ class PlannedFn(Function):
             c = _ShimCtx(nig)
             c.static = True
             outs, e.fwd = _record(dev, tensors, e.pool, lambda: node.forward(c, *args))
+            if e.fwd is None:                     # refused (foreign kernels in the body): this pass WAS a full eager pass
+                e.refused, e.done, e.live = True, True, None
+                c.static = False
+                ctx.entry, ctx.ext, ctx.args, ctx.shim = None, None, None, c
+                if not c.materialize:
+                    ctx.set_materialize_grads(False)
+                return outs
             e.ctx = c
             e.single = torch.is_tensor(outs)
             outs_t = (outs,) if e.single else tuple(outs)
             e.outs = tuple(o.detach() if torch.is_tensor(o) else o for o in outs_t)
             e.params = [a for a in args if torch.is_tensor(a) and _is_param(a)]
+            e.param_ptrs = tuple(p.data_ptr() for p in e.params)
             e.param_pos = [i for i, a in enumerate(args) if torch.is_tensor(a) and _is_param(a)]
         else:
             e.fwd.run(tensors)
@@ -517,8 +569,11 @@ class PlannedFn(Function):
             dev = ext[0].device
             grads, plan = _record(dev, ext, e.pool, lambda: node.backward(e.ctx, *gouts))
             grads = tuple(grads)
-            e.bwd[bkey] = (plan, tuple(g.detach() if torch.is_tensor(g) else g for g in grads))
-            e.grad_ptrs.update(g.data_ptr() for g in grads if torch.is_tensor(g))
+            if plan is None:
+                e.refused = True                  # later forwards of this signature go eager
+            else:
+                e.bwd[bkey] = (plan, tuple(g.detach() if torch.is_tensor(g) else g for g in grads))
+                e.grad_ptrs.update(g.data_ptr() for g in grads if torch.is_tensor(g))
         else:
             plan, static = got
             plan.run(ext)

@@ -191,8 +191,24 @@ def time_sine_table(rows: int, d: int = 256) -> np.ndarray:
     return te
 
 
+_VALUE_CACHE: Dict[Tuple[str, Tuple[int, ...]], np.ndarray] = {}
+_VALUE_CACHE_LIMIT = 1 << 28      # elements (1 GB of fp32): the 82 M-parameter model three times over
+
+
 def synth_value(name: str, shape: Tuple[int, ...]) -> np.ndarray:
-    """Value of one state-dict entry, from its name alone."""
+    """Value of one state-dict entry, from its name alone.  Memoised (read-only arrays): a test process builds the
+    82 M-parameter model dozens of times and the counter hash costs ~3 s per model."""
+    key = (canonical_name(name), tuple(int(d) for d in shape))
+    v = _VALUE_CACHE.get(key)
+    if v is None:
+        v = _synth_value(*key)
+        v.setflags(write=False)
+        if sum(a.size for a in _VALUE_CACHE.values()) + v.size <= _VALUE_CACHE_LIMIT:
+            _VALUE_CACHE[key] = v
+    return v
+
+
+def _synth_value(name: str, shape: Tuple[int, ...]) -> np.ndarray:
     name = canonical_name(name)
     n = int(np.prod(shape))
     leaf = name.rsplit(".", 1)[-1]
@@ -233,7 +249,7 @@ def synth_state_dict(entries: Iterable[Tuple[str, Tuple[int, ...]]] | None = Non
                      device: str | torch.device = "cpu", **kw) -> Dict[str, torch.Tensor]:
     if entries is None:
         entries = hot_path_entries(**kw)
-    return {k: torch.from_numpy(synth_value(k, s)).to(device) for k, s in entries}
+    return {k: torch.from_numpy(synth_value(k, s).copy()).to(device) for k, s in entries}
 
 
 def fill_module_(module: torch.nn.Module, skip_prefixes: Tuple[str, ...] = ("text_encoder.",)) -> List[str]:
@@ -243,7 +259,7 @@ def fill_module_(module: torch.nn.Module, skip_prefixes: Tuple[str, ...] = ("tex
         for k, v in module.state_dict().items():
             if k.startswith(skip_prefixes) or not v.dtype.is_floating_point:
                 continue
-            v.copy_(torch.from_numpy(synth_value(k, tuple(v.shape))).to(v.device))
+            v.copy_(torch.from_numpy(synth_value(k, tuple(v.shape)).copy()).to(v.device))
             filled.append(k)
     return filled
 
@@ -283,3 +299,47 @@ def synth_targets(T: int, seed: int = 0):
     jit = hash_uniform(f"targets/{T}", (e - s) * 4, salt=seed).reshape(e - s, 4) * 0.05
     boxes = torch.tensor([0.5, 0.5, 0.2, 0.3]) + torch.from_numpy(jit)
     return act, boxes.float()
+
+
+def synth_clip(T: int, res, pad=None):
+    """frames [T,3,H,W] + padding mask [T,H,W]; res = side of a square clip or (H, W).  pad="ragged": frames of
+    different extents inside one padded tensor, as NestedTensor.from_tensor_list builds them (utils/misc.py:67-94: zeros
+    + mask = True): the last frame loses its right quarter, frame 1 its bottom eighth, frame 2 both."""
+    H, W = (res, res) if isinstance(res, int) else res
+    frames = synth_frames(T, max(H, W))[:, :, :H, :W].contiguous()
+    mask = torch.zeros(T, H, W, dtype=torch.bool)
+    if pad == "ragged":
+        mask[T - 1, :, W - W // 4:] = True
+        mask[1 % T, H - H // 8:, :] = True
+        mask[2 % T, H - H // 8:, :] = True
+        mask[2 % T, :, W - W // 4:] = True
+        frames = frames.masked_fill(mask[:, None], 0.0)
+    return frames, mask, H, W
+
+
+def sample_indices(name: str, numel: int, k: int = 1024) -> np.ndarray:
+    """Up to k distinct flat indices into a tensor of `numel` elements, a pure function of (name, numel, k): the
+    gradient fixtures keep these elements of every parameter gradient (a flat stride would always hit the same filter
+    tap / input channel of a conv weight).  Sorted, int64."""
+    if numel <= k:
+        return np.arange(numel, dtype=np.int64)
+    seed = np.uint64(fnv1a64("sample/" + canonical_name(name)))
+    with np.errstate(over="ignore"):
+        x = _splitmix(np.arange(2 * k, dtype=np.uint64) * _GOLDEN + seed)
+    idx = np.unique((x % np.uint64(numel)).astype(np.int64))
+    if idx.size > k:
+        idx = idx[np.linspace(0, idx.size - 1, k).astype(np.int64)]
+    return idx
+
+
+# model-level parity cases: name -> (T, resolution or (H, W), text tokens, padding, with backward).  The fixtures
+# tests/golden/model_<name>.npz hold what the imported reference computes for them (tests/golden/make_golden.py).
+MODEL_CASES = {
+    "C1": (8, 224, 10, None, True),
+    "C2": (32, 416, 10, None, False),
+    "C3": (64, 448, 10, None, True),
+    "C5": (128, 448, 40, None, False),
+    "SQ8_ragged": (8, 224, 10, "ragged", True),
+    "NS8": (8, (405, 720), 10, None, True),
+    "NS8_ragged": (8, (405, 720), 10, "ragged", True),
+}

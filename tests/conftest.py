@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The GPU suite runs evidence first: kernels -> whole-model parity -> launch plans -> optimizer / loader /
+# dispatcher -> data parallel -> the bench.py subprocess runs last.  Files not listed keep their place after the parity
+# block.  (The CPU selection is distributed over xdist workers, where order does not matter.)
+_GPU_ORDER = ("test_library.py", "test_ops.py", "test_map2d.py", "test_model_parity.py", "test_plans.py", "test_optim.py",
+              "test_loader.py", "test_torch_ops.py", "test_dist.py", "test_dp_model.py", "test_bench_dp.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return _GPU_ORDER.index(name) if name in _GPU_ORDER else _GPU_ORDER.index("test_plans.py")
+    items.sort(key=rank)          # stable: the order inside a file is the file's own
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -332,6 +332,126 @@ def run_config(name: str, with_backward: bool):
     return g
 
 
+# ----------------------------------------------------------------------------
+# model-level cases at every size the GPU tests use (round 4): the reference itself, fp32 and — for the cases with a
+# backward — a second run in fp64, the "exact arithmetic" yardstick the calibrated gradient bound of
+# tests/test_model_parity.py is built on.  SURVEY.md §8c: larger configs store outputs only; gradients are kept as a
+# per-tensor sample (synth.sample_indices: <= 1024 elements) + the full-tensor norms.
+# ----------------------------------------------------------------------------
+def _run_reference_case(name: str, dtype: torch.dtype):
+    T, res, L, pad, bwd = synth.MODEL_CASES[name]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cfg, model, criterion, weight_dict, post, text = build_reference(L)
+        from utils.misc import NestedTensor
+        from utils.bounding_box import BoxList
+        if dtype == torch.float64:
+            model.double()
+            (tm, tmem, tx), tcls = text
+            model.text_encoder.text = ((tm, tmem.double(), tx), tcls.double())
+            # PositionEmbeddingSine builds its table with dtype=torch.float32 whatever the default is
+            # (vision_model/position_encoding.py:74-81): hand the SAME values on as fp64 so the fp64 Linear layers accept
+            # them (a forward hook on the reference module; no reference code is changed)
+            model.vis_encoder.register_forward_hook(lambda m, i, o: (o[0], o[1].double()))
+        frames, mask, H, W = synth.synth_clip(T, res, pad)
+        videos = NestedTensor(frames.to(dtype), mask, [T])
+        act, boxes = synth.synth_targets(T)
+        targets = [{"actioness": act, "boxs": BoxList(boxes.to(dtype), (W, H), mode="xyxy")}]
+        stages = {}
+        model.vis_encoder[0].body.layer4.register_forward_hook(lambda m, i, o: stages.__setitem__("layer4", o))
+        model.ground_encoder.register_forward_hook(lambda m, i, o: stages.__setitem__("enc", o))
+        model.ground_decoder.register_forward_hook(lambda m, i, o: stages.__setitem__("dec", o))
+        with (torch.enable_grad() if bwd else torch.no_grad()):
+            out = model(videos, ["synthetic query"])
+        r = {"T": T, "H": H, "W": W, "L": L}
+        r["out"] = {k: out[k].detach().clone() for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights")}
+        r["aux"] = [{k: a[k].detach().clone() for k in r["out"]} for a in out["aux_outputs"]]
+        (hs, ref), (time_hs, weights) = stages["dec"]
+        r["stage"] = {"layer4": stages["layer4"].detach(), "encoded_memory": stages["enc"]["encoded_memory"].detach(),
+                      "frames_cls": stages["enc"]["frames_cls"].detach(), "hs": hs.detach(), "ref": ref.detach(),
+                      "time_hs": time_hs.detach()}
+        sizes = torch.tensor([[float(H), float(W)]], dtype=dtype).repeat(T, 1)
+        pb, steds = post(out, sizes, [list(range(100, 100 + T))], [T])     # before the criterion edits pred_boxes in place
+        r["post_boxes"], r["post_sted"] = pb.detach().clone(), steds
+        if bwd:
+            losses = criterion(out, targets, [T])
+            assert set(losses.keys()) == set(weight_dict.keys())
+            total = sum(losses[k] * weight_dict[k] for k in losses)
+            total.backward()
+            r["loss"] = {k: losses[k].item() for k in sorted(losses)}
+            r["loss_total"] = total.item()
+            r["grads"], r["unused"] = {}, []
+            for n_, p in model.named_parameters():
+                if n_.startswith("text_encoder."):
+                    continue
+                if p.grad is None:
+                    if p.requires_grad:
+                        r["unused"].append(n_)
+                    continue
+                r["grads"][n_] = p.grad.detach()
+        return r
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def model_case_fixture(name: str):
+    T, res, L, pad, bwd = synth.MODEL_CASES[name]
+    r32 = _run_reference_case(name, torch.float32)
+    g = {"meta/config": np.asarray([r32["T"], r32["H"], r32["W"], r32["L"]], dtype=np.int64),
+         "meta/pad": np.asarray(pad or ""), "meta/backward": np.asarray(bool(bwd))}
+    for k, v in r32["out"].items():
+        g[f"out/{k}"] = v.numpy()
+        for i, a in enumerate(r32["aux"]):
+            g[f"out/aux{i}/{k}"] = a[k].numpy()
+    g["post/boxes"] = r32["post_boxes"].numpy()
+    g["post/sted"] = np.asarray(r32["post_sted"], dtype=np.int64)
+    for k, v in r32["stage"].items():
+        g[f"stage/{k}"] = sub(v, 1 << 13)
+        g[f"stage/{k}/absmax"] = np.float32(v.abs().max().item())
+    if not bwd:
+        return g
+    keys = sorted(r32["loss"])
+    g["loss/keys"] = np.asarray(keys)
+    g["loss/values"] = np.asarray([r32["loss"][k] for k in keys], dtype=np.float32)
+    g["loss/total"] = np.float32(r32["loss_total"])
+    g32 = r32["grads"]
+    unused = r32["unused"]
+    del r32
+    import gc
+    gc.collect()
+    r64 = _run_reference_case(name, torch.float64)
+    g64 = r64["grads"]
+    assert list(g64) == list(g32) and r64["unused"] == unused
+    g["loss/values64"] = np.asarray([r64["loss"][k] for k in keys], dtype=np.float64)
+    g["loss/total64"] = np.float64(r64["loss_total"])
+    for k, v in r64["out"].items():
+        g[f"out64/{k}"] = v.numpy()
+    g["post/sted64"] = np.asarray(r64["post_sted"], dtype=np.int64)
+    names = list(g32)
+    offs, s32, s64 = [0], [], []
+    n32, n64, e32 = [], [], []
+    for n_ in names:
+        a, b = g32[n_].reshape(-1), g64[n_].reshape(-1)
+        idx = torch.from_numpy(synth.sample_indices(n_, a.numel()))
+        s32.append(a[idx].numpy().astype(np.float32))
+        s64.append(b[idx].numpy().astype(np.float32))        # fp64 run, stored to fp32 precision (6e-8 relative)
+        offs.append(offs[-1] + idx.numel())
+        n32.append(a.double().norm().item())
+        n64.append(b.norm().item())
+        e32.append((a.double() - b).norm().item())
+    g["grad/names"] = np.asarray(names)
+    g["grad/unused"] = np.asarray(unused)
+    g["grad/numel"] = np.asarray([g32[n_].numel() for n_ in names], dtype=np.int64)
+    g["grad/offsets"] = np.asarray(offs, dtype=np.int64)
+    g["grad/sample32"] = np.concatenate(s32)
+    g["grad/sample64"] = np.concatenate(s64)
+    g["grad/norm32"] = np.asarray(n32, dtype=np.float64)       # full-tensor L2 norms
+    g["grad/norm64"] = np.asarray(n64, dtype=np.float64)
+    g["grad/err32"] = np.asarray(e32, dtype=np.float64)        # || fp32 reference - fp64 reference ||, full tensor
+    return g
+
+
 def op_level_vectors():
     """Known-answer vectors for the small closed-form ops of the path."""
     install_stubs()
@@ -360,8 +480,8 @@ def op_level_vectors():
     # DAB custom MHA: 1 query per batch row, k-dim 512, v-dim 256, partially masked keys
     torch.manual_seed(0)
     mha = MultiheadAttention(512, 8, dropout=0.0, vdim=256).eval()
-    ow = torch.from_numpy(synth.synth_value("op/dab/out_proj.weight", (256, 256)))
-    ob = torch.from_numpy(synth.synth_value("op/dab/out_proj.bias", (256,)))
+    ow = torch.from_numpy(synth.synth_value("op/dab/out_proj.weight", (256, 256)).copy())
+    ob = torch.from_numpy(synth.synth_value("op/dab/out_proj.bias", (256,)).copy())
     with torch.no_grad():
         mha.out_proj.weight.copy_(ow)
         mha.out_proj.bias.copy_(ob)
@@ -442,7 +562,7 @@ def map2d_vectors():
         head = m.TempPredictionHead(cfg).eval()
         with torch.no_grad():
             for k, v in head.state_dict().items():
-                v.copy_(torch.from_numpy(synth.synth_value("map2d_head." + k, tuple(v.shape))))
+                v.copy_(torch.from_numpy(synth.synth_value("map2d_head." + k, tuple(v.shape)).copy()))
             for i, w in enumerate(head.encoder.weights):
                 g[f"map2d/weight{i}"] = w.numpy()
             xh = torch.from_numpy(synth.hash_normal("op/map2d/xh", 2 * 1 * 20 * 64).reshape(2, 1, 20, 64))
@@ -453,7 +573,7 @@ def map2d_vectors():
         def fill(hd, prefix):
             with torch.no_grad():
                 for k, v in hd.state_dict().items():
-                    v.copy_(torch.from_numpy(synth.synth_value(prefix + k, tuple(v.shape))))
+                    v.copy_(torch.from_numpy(synth.synth_value(prefix + k, tuple(v.shape)).copy()))
 
         def train_vectors(hd, x, tag, full_grads=True):
             """train mode (map2d_head.py:122-124: raw scores) + the gradients of sum(scores * G) — what a loss on the map
@@ -513,6 +633,17 @@ def main():
         print("eval.npz written")
         return
     torch.set_num_threads(8)
+    if sys.argv[1:2] == ["model"]:
+        # python tests/golden/make_golden.py model [CASE ...]  -> tests/golden/model_<CASE>.npz (C3: ~10 minutes, 40 GB)
+        import time
+        for name in (sys.argv[2:] or list(synth.MODEL_CASES)):
+            t0 = time.time()
+            g = model_case_fixture(name)
+            path = os.path.join(out_dir, f"model_{name}.npz")
+            np.savez_compressed(path, **g)
+            print(f"model_{name}.npz written: {len(g)} arrays, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s",
+                  flush=True)
+        return
     np.savez_compressed(os.path.join(out_dir, "ops.npz"), **op_level_vectors())
     print("ops.npz written")
     which = sys.argv[1:] or ["C1"]

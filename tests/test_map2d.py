@@ -26,7 +26,7 @@ def _map2d_head(dev, big):
     assert [k for k in head.state_dict().keys()] == list(g["map2d/head/keys"])       # the reference's parameter names
     with torch.no_grad():
         for k, v in head.state_dict().items():
-            v.copy_(torch.from_numpy(synth.synth_value("map2d_head." + k, tuple(v.shape))))
+            v.copy_(torch.from_numpy(synth.synth_value("map2d_head." + k, tuple(v.shape)).copy()))
     head.to(dev).eval()
     close(head.weight0, torch.from_numpy(g["map2d/weight0"]), 1e-6, "mask weight 0")
     close(head.weight1, torch.from_numpy(g["map2d/weight1"]), 1e-6, "mask weight 1")
@@ -75,7 +75,7 @@ def _map2d_head(dev, big):
 def _fill(head, prefix):
     with torch.no_grad():
         for k, v in head.state_dict().items():
-            v.copy_(torch.from_numpy(synth.synth_value(prefix + k, tuple(v.shape))))
+            v.copy_(torch.from_numpy(synth.synth_value(prefix + k, tuple(v.shape)).copy()))
 
 
 def _train_and_grads(dev, g, head, tag, tol, norms_only=False):

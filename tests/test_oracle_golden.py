@@ -106,8 +106,8 @@ def test_op_vectors(golden_dir):
     _close(O.inverse_sigmoid(torch.from_numpy(g["invsig/x"])).numpy(), g["invsig/y"], 1e-6, "invsig")
     _close(O.pos_sine_2d(torch.from_numpy(g["pos2d/mask"])).numpy(), g["pos2d/pos"], 1e-6, "pos2d")
     _close(synth.time_sine_table(301)[:10], g["seqsine/te"], 1e-6, "seq sine")
-    sd = {"x.out_proj.weight": torch.from_numpy(synth.synth_value("op/dab/out_proj.weight", (256, 256))),
-          "x.out_proj.bias": torch.from_numpy(synth.synth_value("op/dab/out_proj.bias", (256,)))}
+    sd = {"x.out_proj.weight": torch.from_numpy(synth.synth_value("op/dab/out_proj.weight", (256, 256)).copy()),
+          "x.out_proj.bias": torch.from_numpy(synth.synth_value("op/dab/out_proj.bias", (256,)).copy())}
     q = torch.from_numpy(synth.hash_normal("op/dab/q", 3 * 512).reshape(1, 3, 512))
     k = torch.from_numpy(synth.hash_normal("op/dab/k", 11 * 3 * 512).reshape(11, 3, 512))
     v = torch.from_numpy(synth.hash_normal("op/dab/v", 11 * 3 * 256).reshape(11, 3, 256))
