@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   const int kstep = p.par ? 2 : 1;
   const int kh0 = p.par ? ((py + g.off) & 1) : 0, kw0 = p.par ? ((px + g.off) & 1) : 0;
   const int nkh = kh0 < g.KH ? (g.KH - kh0 + kstep - 1) / kstep : 0, nkw = kw0 < g.KW ? (g.KW - kw0 + kstep - 1) / kstep : 0;
-  const int nk = p.par ? nkh * nkw * (g.C / BK) : p.K / BK;
+  const int nk = (p.debug & 16) ? 0 : (p.par ? nkh * nkw * (g.C / BK) : p.K / BK);   // (debug 16: epilogue only)
 
   // ---- DMA bookkeeping: piece q = wave + NW i covers rows 16 q .. 16 q + 15 of a plane; lane -> row 16 q + (lane >> 2),
   // LDS chunk (lane & 3) which holds SOURCE chunk (lane & 3) ^ ((row >> 2) & 3)
@@ -336,6 +336,40 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
       F.a[pi_][tm] = *reinterpret_cast<const bf16x8*>((SB) + fa_off[KS] + pi_ * PLANE_A + tm * 2048);   \
   }
 
+  // ---- epilogue addressing (declared ahead of the K loop: its first operand block is requested from inside the loop)
+  // per wave, one 32-row block of its tile at a time through a private LDS block
+  float* ew = reinterpret_cast<float*>(smem + wave * EPI_WAVE);
+  constexpr int LPR = TN * 4;          // lanes per output row (8 columns each)
+  constexpr int RPP = 64 / LPR;        // rows per pass
+  const int erow = lane / LPR, ecol = (lane % LPR) * 8;
+  const int n = n0 + wn * TN * 32 + ecol;
+  // The epilogue's global operands — residual planes and the ReLU bit mask — of a 32-row block are requested BEFORE
+  // the block goes through LDS, and those of block tm + 1 before block tm is processed: the K <= 512 layers are bound
+  // by exactly these loads (one HBM round trip per pass otherwise: 4-16 serial round trips per tile).
+  constexpr int NPS = 32 / RPP;
+  struct Pre { bf16x8 r[NPS][NP]; unsigned bits[NPS]; int m[NPS]; };
+  const __bf16* Rp[3] = {p.Rh, p.Rl, stcat_plane(p.Rh, p.Rl, 2)};
+  __bf16* Cp[3] = {p.Ch, p.Cl, stcat_plane(p.Ch, p.Cl, 2)};
+  __bf16* C2p[3] = {p.C2h, p.C2l, stcat_plane(p.C2h, p.C2l, 2)};
+  auto prefetch = [&](Pre& q, int tm) {
+    STCAT_UNROLL
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int mrow = m0 + wm * TM * 32 + tm * 32 + ps * RPP + erow;
+      int m = mrow;                      // output row = pixel index
+      if (p.par && mrow < Mc) {
+        const int nb = mrow / (OHc * OWc), rem = mrow - nb * OHc * OWc, oh = rem / OWc, ow = rem - oh * OWc;
+        m = (nb * g.OH + 2 * oh + py) * g.OW + 2 * ow + px;
+      }
+      q.m[ps] = m;
+      if (mrow < Mc && !(p.debug & (2 | 32))) {     // (debug 32: no epilogue loads)
+        if (p.Rh) {
+          STCAT_UNROLL
+          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = STCAT_LOAD_STREAM(reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n));
+        }
+        if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
+      }
+    }
+  };
   STCAT_PL_ACC_INIT
   constexpr int NMMA = (F32 ? 4 : PlProd<NP>::N) * TM * TN, NRD = NPL * (TM + TN);
   constexpr int NDMA = NPL * ((QA >= NW ? RQA : 1) + (QB >= NW ? RQB : 1));
@@ -346,9 +380,23 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   STCAT_S_BARRIER();     // has fewer than 8 DMA pieces)
   STCAT_SCHED_FENCE();
   STCAT_PL_READ_FRAG(fa, smem, 0)
+  // The epilogue's first block of global operands (residual planes / bit mask) is requested TWO K-tiles before the K loop
+  // ends: one full HBM round trip per tile (2-3 us of a 25-40 us tile on the K <= 512 layers) leaves the critical path.
+  // (three-plane tiles only: the 256 x 256 two-plane tile has no registers to spare; EARLY_PRE is a compile-time switch)
+  constexpr bool DB = !(BM == 256 && BN == 256);
+  // MEASURED NEUTRAL (round 4, same-box A/B on every 1x1 shape, profiles/r04_plane_gemm_experiments.log: +-1 %): the
+  // tile is not waiting for its first epilogue operands.  Kept as an opt-in compile-time switch.
+#ifdef STCAT_PL_EARLY_PRE
+  constexpr bool EARLY_PRE = DB && NP == 3 && !F32;
+#else
+  constexpr bool EARLY_PRE = false;
+#endif
+  Pre pre[2];
+  const int kt_pre = nk >= 2 ? nk - 2 : -1;
   for (int kt = 0; kt < nk; ++kt) {
     const char* sb = smem + (kt & 1) * STAGE;
     const char* sn = smem + ((kt + 1) & 1) * STAGE;
+    if (EARLY_PRE && kt == kt_pre) prefetch(pre[0], 0);
     // P0: k-step 1 fragments are read among the MFMAs of k-step 0
     STCAT_PL_READ_FRAG(fb, sb, 1)
     STCAT_PL_INTERLEAVE(NMMA, NRD, 0)
@@ -371,12 +419,6 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   STCAT_S_BARRIER();
   STCAT_SCHED_FENCE();
 
-  // ---- epilogue: per wave, one 32-row block of its tile at a time through a private LDS block
-  float* ew = reinterpret_cast<float*>(smem + wave * EPI_WAVE);
-  constexpr int LPR = TN * 4;          // lanes per output row (8 columns each)
-  constexpr int RPP = 64 / LPR;        // rows per pass
-  const int erow = lane / LPR, ecol = (lane % LPR) * 8;
-  const int n = n0 + wn * TN * 32 + ecol;
   float sc[8], bi[8], ms[8], s2[8];
   STCAT_UNROLL
   for (int e = 0; e < 8; ++e) {
@@ -385,37 +427,8 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
     ms[e] = p.mscale ? p.mscale[n + e] : 1.f;
     s2[e] = p.c2scale ? p.c2scale[n + e] : 1.f;
   }
-  // The epilogue's global operands — residual planes and the ReLU bit mask — of a 32-row block are requested BEFORE
-  // the block goes through LDS, and those of block tm + 1 before block tm is processed: the K <= 512 layers are bound
-  // by exactly these loads (one HBM round trip per pass otherwise: 4-16 serial round trips per tile).
-  constexpr int NPS = 32 / RPP;
-  struct Pre { bf16x8 r[NPS][NP]; unsigned bits[NPS]; int m[NPS]; };
-  const __bf16* Rp[3] = {p.Rh, p.Rl, stcat_plane(p.Rh, p.Rl, 2)};
-  __bf16* Cp[3] = {p.Ch, p.Cl, stcat_plane(p.Ch, p.Cl, 2)};
-  __bf16* C2p[3] = {p.C2h, p.C2l, stcat_plane(p.C2h, p.C2l, 2)};
-  Pre pre[2];
-  auto prefetch = [&](Pre& q, int tm) {
-    STCAT_UNROLL
-    for (int ps = 0; ps < NPS; ++ps) {
-      const int mrow = m0 + wm * TM * 32 + tm * 32 + ps * RPP + erow;
-      int m = mrow;                      // output row = pixel index
-      if (p.par && mrow < Mc) {
-        const int nb = mrow / (OHc * OWc), rem = mrow - nb * OHc * OWc, oh = rem / OWc, ow = rem - oh * OWc;
-        m = (nb * g.OH + 2 * oh + py) * g.OW + 2 * ow + px;
-      }
-      q.m[ps] = m;
-      if (mrow < Mc && !(p.debug & 2)) {
-        if (p.Rh) {
-          STCAT_UNROLL
-          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = STCAT_LOAD_STREAM(reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n));
-        }
-        if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
-      }
-    }
-  };
   // (the 256 x 256 two-plane tile has no registers left for the second set; the three-plane 256 x 128 tile does: 212 VGPRs)
-  constexpr bool DB = !(BM == 256 && BN == 256);
-  if (DB) prefetch(pre[0], 0);
+  if (DB && !(EARLY_PRE && kt_pre >= 0)) prefetch(pre[0], 0);
   STCAT_UNROLL
   for (int tm = 0; tm < TM; ++tm) {
     if (!DB) prefetch(pre[0], tm);
@@ -469,7 +482,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
           for (int e = 0; e < 8; ++e) bits |= (x[e] > 0.f ? 1u : 0u) << e;
           p.Mo[((long)m * p.ldc + n) >> 3] = (unsigned char)bits;
         }
-        if (p.Ch) {
+        if (p.Ch && !((p.debug & 64) && x[0] != 12345.f)) {     // (debug 64: no plane stores)
           bf16x8 o8[NP];
           stcat_split8n<NP>(x, o8);
           STCAT_UNROLL

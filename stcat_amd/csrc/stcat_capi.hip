@@ -1104,7 +1104,7 @@ int stcat_debug_force_pl_tile(int index) {
 }
 
 int stcat_debug_pl_flags(int flags) {
-  g_pl_debug = flags & 3;
+  g_pl_debug = flags & ~4;             // bits 0,1,3.. : timing experiments (PlParams::debug, stagger)
   g_pl3_small = (flags & 4) ? 1 : 0;   // bit 2: three-plane short reductions on the two-workgroup 128 x 64 tile
   return 0;
 }

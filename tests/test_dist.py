@@ -187,3 +187,57 @@ def test_bucket_layout_has_a_small_tail():
     assert sum(sizes) == 10 * 64 * 64 * 4
     assert sizes[-1] <= 20 * 1024 and max(sizes) <= 64 * 1024
     assert [n for n, _ in red.buckets[-1]["params"]] == ["0.weight"]          # the first layer's gradient is ready last
+
+
+def _rccl_single_rank(collective, q):
+    """subprocess body: the reducer over RCCL at world size 1 (what a 1-GPU box can run of the N > 1 path)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), STCAT_DP_COLLECTIVE=collective)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from stcat_amd.dist import init_rccl_process_group
+    init_rccl_process_group(dev, rank=0, world_size=1)
+    torch.manual_seed(0)
+    model = Toy().to(dev)
+    red = GradBucketReducer(model, bucket_mb=0.002, extra_numel=1000, force_comm=True)
+    assert red.collective == collective and all(b["padded"] % 64 == 0 for b in red.buckets)
+    out = []
+    for step in range(2):
+        red.zero_grad()
+        x = torch.full((2, 8, 5, 5), float(1 + step), device=dev)
+        model(x).square().sum().backward()
+        red.finish()
+        out.append({n: p.grad.detach().cpu().clone() for n, p in live_trainable(model.named_parameters())})
+    q.put(out)
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpu_reducer_rs_ag_equals_allreduce_single_rank():
+    """STCAT_DP_COLLECTIVE=rs_ag (reduce-scatter + all-gather per padded bucket, round 4) against the default all-reduce,
+    both over RCCL with one rank: the mean over one rank is the identity, so both must return the plain gradients — what
+    is exercised is the real RCCL call sequence (async reduce_scatter_tensor -> all_gather_into_tensor on one stream, AVG
+    inside the collective, padded flat buckets, the dummy message launched behind its trigger bucket)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    res = {}
+    for coll in ("allreduce", "rs_ag"):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_single_rank, args=(coll, q))
+        p.start()
+        res[coll] = q.get(timeout=300)
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    model = Toy()
+    for step in range(2):
+        for prm in model.parameters():
+            prm.grad = None
+        model(torch.full((2, 8, 5, 5), float(1 + step))).square().sum().backward()
+        for n, prm in live_trainable(model.named_parameters()):
+            for coll in ("allreduce", "rs_ag"):
+                got = res[coll][step][n]
+                assert torch.allclose(got, prm.grad, rtol=1e-4, atol=1e-5), (coll, step, n)

@@ -92,6 +92,7 @@ class Ref:
         self.out, self.aux, self.post_boxes, self.post_sted = {}, [], None, None
         self.losses = None
         self.grads = None        # name -> (sample of the fp32 gradient, sample of the fp64 gradient, numel): float64 arrays
+        self.sampled = True      # fixtures keep synth.sample_indices elements per tensor; oracle runs keep every element
         self.dims = None         # (T, H, W, L, pad)
 
     @staticmethod
@@ -131,10 +132,9 @@ class Ref:
         r.post_boxes, r.post_sted, r.losses = boxes, [sted], losses
         if with_backward:
             g64 = _run_oracle(T, res, L, True, torch.float64, pad, sites)[4]
-            r.grads = {}
-            for n, g in g32.items():
-                idx = torch.from_numpy(synth.sample_indices(n, g.numel()))
-                r.grads[n] = (g.reshape(-1)[idx].double().numpy(), g64[n].reshape(-1)[idx].double().numpy(), g.numel())
+            r.sampled = False
+            r.grads = {n: (g.reshape(-1).double().numpy(), g64[n].reshape(-1).double().numpy(), g.numel())
+                       for n, g in g32.items()}
         return r
 
 
@@ -256,8 +256,10 @@ def _compare(hip, ref: Ref, with_backward=True, grad_slack=1.0, grad_caps=None, 
         # arithmetic as the fp32 reference is (x3 + 1e-3), per tensor, in relative L2.  Absolute floor:
         # key-side attention biases have an exactly-zero gradient (softmax shift invariance).
         assert grads[hip_name].numel() == numel, (name, grads[hip_name].shape, numel)
-        idx = torch.from_numpy(synth.sample_indices(name, numel))
-        a = grads[hip_name].reshape(-1)[idx].double().numpy()
+        a = grads[hip_name].reshape(-1)
+        if ref.sampled:
+            a = a[torch.from_numpy(synth.sample_indices(name, numel))]
+        a = a.double().numpy()
         floor = GRAD_ABS_FLOOR * g64.size ** 0.5 / GRAD_TOL
         nrm = float(np.linalg.norm(g64)) + floor
         e_hip = float(np.linalg.norm(a - g64)) / nrm

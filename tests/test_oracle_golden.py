@@ -141,3 +141,54 @@ def test_linear_interp_against_reference_golden(golden_dir):
     assert np.array_equal(bx.numpy(), g["interp/out_boxes"])
     full1, bx1 = linear_interp([7], torch.tensor([[1.0, 2.0, 3.0, 4.0]]))
     assert full1 == g["interp/single_ids"].tolist() and bx1.shape == (1, 4)
+
+
+def _oracle_case(name, dtype):
+    T, res, L, pad, bwd = synth.MODEL_CASES[name]
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        sd = {k: v.to(dtype).requires_grad_(True) for k, v in synth.synth_state_dict().items()}
+        frames, mask, H, W = synth.synth_clip(T, res, pad)
+        (tm, tmem, _), tcls = synth.synth_text(L)
+        out = O.stcat_forward(sd, frames.to(dtype), mask, ((tm, tmem.to(dtype), None), tcls.to(dtype)))
+        grads = None
+        if bwd:
+            act, tb = synth.synth_targets(T)
+            O.total_loss(O.criterion(out, act, tb.to(dtype))).backward()
+            grads = {k: v.grad for k, v in sd.items() if v.grad is not None}
+        return out, grads
+    finally:
+        torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("name", ["C1"] + (["SQ8_ragged", "NS8_ragged", "C3"] if os.environ.get("STCAT_SLOW") else []))
+def test_oracle_against_model_fixture(golden_dir, name):
+    """The round-4 model fixtures (tests/golden/model_<case>.npz: the imported reference in fp32 AND fp64) pin the oracle
+    in both precisions: outputs, and every gradient tensor at the fixture's sample positions.  C1 runs in the CPU suite;
+    STCAT_SLOW=1 adds the padded square clip, the padded 405 x 720 clip and C3 (minutes, ~40 GB).  Measured (C1 / padded
+    square): fp64 3.3e-8 / 3.5e-8 worst tensor (= the fixture's fp32 storage), fp32 median 3e-7, worst 4.8e-3 / 7.2e-3."""
+    g = _load(golden_dir, f"model_{name}.npz")
+    names = [str(n) for n in g["grad/names"]]
+    offs = g["grad/offsets"]
+    for dtype, okey, skey, tol in ((torch.float32, "out/", "grad/sample32", 2e-5), (torch.float64, "out64/", "grad/sample64", 2e-6)):
+        out, grads = _oracle_case(name, dtype)
+        for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights"):
+            _close(out[k].detach().numpy(), g[okey + k], tol, f"{name} {dtype} {k}")
+        errs = []
+        for i, n in enumerate(names):
+            gr = grads[synth.canonical_name(n)].reshape(-1)
+            idx = torch.from_numpy(synth.sample_indices(n, gr.numel()))
+            ref = g[skey][offs[i]:offs[i + 1]].astype(np.float64)
+            got = gr[idx].double().numpy()
+            errs.append(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-6 * ref.size ** 0.5))
+        errs = np.sort(np.asarray(errs))
+        print(f"{name} {dtype}: oracle vs reference gradient samples, rel-L2 median {errs[len(errs) // 2]:.2e} max {errs[-1]:.2e}")
+        if dtype == torch.float64:
+            # exact arithmetic on both sides (the fixture stores fp64 values to fp32 precision)
+            assert errs[-1] <= 1e-6, (name, errs[-5:])
+        else:
+            # two fp32 evaluations of this chain (module tree vs functional restatement: other summation orders, other
+            # thread partitions) differ by ReLU-kink flips: as far apart as the fp32 reference is from its fp64 run
+            # (C1: layer2 / layer3 tensors 1e-2 .. 3e-2) — the fp64 comparison above is the sharp one
+            assert errs[len(errs) // 2] <= 1e-5 and errs[-1] <= 5e-2, (name, errs[len(errs) // 2], errs[-5:])
