@@ -84,7 +84,7 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
                 L.call("stcat_linear_dgrad_acc", g.data_ptr(), w.data_ptr(), L._ptr(add), dx.data_ptr(), M, N, K, N, K, st)
             else:
                 dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
-                wt = ops.weight_transpose(w.view(N, 1, K)) if M > 256 else None
+                wt = ops.LINEAR_WT.get(w) if M > 256 else None
                 L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), L._ptr(add), L._ptr(wt), dx.data_ptr(), M, N, K, N, K, st)
         if dw is None:
             dw = ops._zeros(g, N, K)

@@ -380,6 +380,7 @@ class StgLossFn(Function):
         boxes, sted, w, act, wmat = ctx.saved_tensors
         if gvec is None and gtotal is None:
             return None, None, None, None, None, None
+        LINEAR_WT.refresh_all(boxes)      # the first backward node of a step: every Linear W^T of the step in one launch
         gvec, gtotal = _c(gvec), _c(gtotal)
         d_boxes, d_sted, d_w = torch.empty_like(boxes), torch.empty_like(sted), torch.empty_like(w)
         d_act = torch.empty_like(act) if act is not None else None
@@ -422,7 +423,7 @@ class LinearFn(Function):
         if N % 64 == 0:
             if ctx.needs_input_grad[0]:
                 dx = _empty(g, M, K)
-                wt = weight_transpose(w.view(N, 1, K)) if M > 256 else None
+                wt = LINEAR_WT.get(w) if M > 256 else None
                 L.call("stcat_linear_dgrad", g.data_ptr(), w.data_ptr(), None, L._ptr(wt), dx.data_ptr(), M, N, K, N,
                        K, st)
             want_db = ctx.has_b and ctx.needs_input_grad[2]
@@ -1122,6 +1123,63 @@ class WeightTransposer:
             self.total, self.key, self.n = blk, key, len(weights)
         L.call("stcat_weight_transpose_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(weights[0]))
         return self.wts
+
+
+class LinearTransposes:
+    """Transposed copies W^T [K, N] of the Linear weights whose data gradient runs on the transposed-operand kernel (rows
+    M > 256: the encoder's projections / FFN, the decoders' memory-side projections — 59 of them per step, each a ~7 us
+    launch on the backward pass's dependent chain before round 4).  Buffers are persistent; `refresh_all` rewrites every
+    registered one with ONE launch (stcat_weight_transpose_multi) and is called by the first backward node of a step
+    (StgLossFn.backward).  `get(w)` returns the copy when it is current — same parameter version, same WEIGHT_EPOCH — and
+    otherwise transposes that one weight on the spot (a loop that never calls refresh_all, e.g. the reference's own
+    criterion in drop-in mode, behaves as before)."""
+
+    def __init__(self):
+        self.entries = {}      # (data_ptr, N, K) -> [weight view, transposed buffer, version, epoch]
+        self.table = None
+        self.total = 0
+        self.dirty = True
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        N, K = w.shape
+        key = (w.data_ptr(), N, K)
+        e = self.entries.get(key)
+        if e is not None and e[2] == w._version and e[3] == WEIGHT_EPOCH and e[1].device == w.device:
+            return e[1]
+        if e is None or e[1].device != w.device:
+            e = self.entries[key] = [w, torch.empty(K, N, device=w.device, dtype=_f32), -1, -1]
+            self.dirty = True
+            if len(self.entries) > 512:                     # (weights that keep moving: start over)
+                self.entries = {key: e}
+        e[0] = w
+        L.call("stcat_weight_transpose", w.data_ptr(), e[1].data_ptr(), N, 1, K, L.stream_of(w))
+        e[2], e[3] = w._version, WEIGHT_EPOCH
+        return e[1]
+
+    def refresh_all(self, like: torch.Tensor) -> None:
+        import numpy as np
+        ents = [e for e in self.entries.values() if e[1].device == like.device]
+        if not ents:
+            return
+        if self.dirty or self.table is None or self.table.device != like.device:
+            dt = np.dtype([("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
+                           ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4")])
+            assert dt.itemsize == L.load().stcat_weight_transpose_entry_bytes()
+            tab = np.zeros(len(ents), dtype=dt)
+            blk = 0
+            for i, (w, wt, _, _) in enumerate(ents):
+                N, K = w.shape
+                nbx, nby = (K + 31) // 32, (N + 31) // 32
+                tab[i] = (w.data_ptr(), wt.data_ptr(), N, 1, K, blk, nbx, nby)
+                blk += nbx * nby
+            self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(like.device)
+            self.total, self.n, self.dirty = blk, len(ents), False
+        L.call("stcat_weight_transpose_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(like))
+        for e in ents:
+            e[2], e[3] = e[0]._version, WEIGHT_EPOCH
+
+
+LINEAR_WT = LinearTransposes()
 
 
 def conv_dgrad_raw(g, w_ohwi, in_shape, stride, pad, add=None, out=None, mask_y=None, mask_scale=None,
