@@ -1162,6 +1162,8 @@ class LinearTransposes:
         if not ents:
             return
         if self.dirty or self.table is None or self.table.device != like.device:
+            if like.is_cuda and torch.cuda.is_current_stream_capturing():
+                return      # (the table upload cannot be captured: the entries stay stale, get() transposes one by one)
             dt = np.dtype([("w", "<u8"), ("wt", "<u8"), ("Cout", "<i4"), ("taps", "<i4"), ("Cin", "<i4"),
                            ("blk0", "<i4"), ("nbx", "<i4"), ("nby", "<i4")])
             assert dt.itemsize == L.load().stcat_weight_transpose_entry_bytes()
