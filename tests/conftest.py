@@ -12,6 +12,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        # four workers share the host's cores: each one's emulator launches and torch CPU ops take their share instead of
+        # every worker spawning one thread per core (measured on 8 cores: the same test 30 s alone, 180-350 s oversubscribed)
+        share = max(1, (os.cpu_count() or 4) // 4)
+        os.environ.setdefault("STCAT_EMU_THREADS", str(share))
+        os.environ.setdefault("OMP_NUM_THREADS", str(share))
+        try:
+            import torch
+            torch.set_num_threads(share)
+        except Exception:
+            pass
 
 
 # The GPU suite runs evidence first: kernels -> whole-model parity -> launch plans -> optimizer / loader /
@@ -36,7 +47,7 @@ def golden_dir():
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
     """`-m "not gpu"` selects the host-emulator suite: independent, CPU-bound tests (the emulator interprets every MFMA),
-    17 minutes in one process.  They run on four pytest-xdist workers unless the caller chose `-n` himself or set
+    ~12 minutes in one process (round 4: the model-level emulator tests run a 5-bottleneck ResNet).  They run on four pytest-xdist workers unless the caller chose `-n` himself or set
     STCAT_TEST_SERIAL=1; the emulator library is built once, here, before the workers start.  The GPU selection is
     never distributed (one GPU, timing-sensitive tests)."""
     if (config.option.markexpr or "").strip() != "not gpu" or os.environ.get("STCAT_TEST_SERIAL"):
