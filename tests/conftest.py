@@ -32,7 +32,22 @@ _GPU_ORDER = ("test_library.py", "test_ops.py", "test_map2d.py", "test_model_par
               "test_loader.py", "test_torch_ops.py", "test_dist.py", "test_dp_model.py", "test_bench_dp.py")
 
 
+# the CPU selection is distributed over workers: its longest tests start first (longest-processing-time order)
+_CPU_SLOW_FIRST = ("test_emu_plans_replay", "test_emu_train_mode_dropout", "test_emu_two_forwards", "test_emu_tiny_clip_bf16x6_planes",
+                   "test_emu_nonsquare", "test_emu_train_mode_against_oracle", "test_oracle_against_model_fixture",
+                   "test_emu_tiny_clip", "test_install_is_a_drop_in", "test_emu_pl_conv", "test_emu_map2d", "test_loss_and_grads")
+
+
 def pytest_collection_modifyitems(config, items):
+    if (config.option.markexpr or "").strip() == "not gpu":
+        def slow_rank(item):
+            for i, key in enumerate(_CPU_SLOW_FIRST):
+                if key in item.name:
+                    return i
+            return len(_CPU_SLOW_FIRST)
+        items.sort(key=slow_rank)
+        return
+
     def rank(item):
         name = os.path.basename(str(item.fspath))
         return _GPU_ORDER.index(name) if name in _GPU_ORDER else _GPU_ORDER.index("test_plans.py")
