@@ -136,8 +136,11 @@ int stcat_weight_planes_entry_bytes(void);
 int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream);
 /* tuning/test hook: force the plane-GEMM tile (0: 256x256, 1: 256x128, 2: 128x256, 3: 128x128, 4: 256x64; -1 = heuristic) */
 int stcat_debug_force_pl_tile(int index);
-/* timing experiments (results are WRONG when set): 1 = weight gradient without its atomics, 2 = forward / data-gradient
- * epilogue without global memory traffic; 0 = off */
+/* timing experiments, bit set (results are WRONG when bits 0, 1, 4, 5 or 6 are set): 1 = weight gradient without its atomics,
+ * 2 = forward / data-gradient epilogue without global memory traffic, 4 = three-plane K <= 512 layers on the two-workgroup
+ * 128 x 64 tile, 8 = phase stagger of the first-round workgroups (flags >> 8 = 10 ns ticks per quarter period; results stay
+ * correct), 16 = no K loop (epilogue only), 32 = no epilogue loads, 64 = no plane stores; 0 = off
+ * (profiles/r04_plane_gemm_experiments.log) */
 int stcat_debug_pl_flags(int flags);
 
 /* ---- position embeddings ------------------------------------------------------------------------ */
