@@ -182,3 +182,101 @@ def test_plan_table_covers_every_launch_entry_point():
             assert fn >= 0, name
             assert lib.stcat_plan_fn_nargs(fn) == len(sig), (name, lib.stcat_plan_fn_nargs(fn), len(sig))
     assert lib.stcat_plan_fn_index(b"stcat_set_mma_mode") == -1
+
+
+class _NodeWithForeignKernel(torch.autograd.Function):
+    """a composite-style node whose body runs an aten kernel on a strided input (x.t().contiguous()): replaying only OUR
+    launches would silently drop that copy"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xt = x.t().contiguous()                    # foreign: an aten copy kernel
+        y = ops.ew(_lib.EW_MUL, xt, w)
+        ctx.save_for_backward(xt, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, w = ctx.saved_tensors
+        return ops.ew(_lib.EW_MUL, dy.contiguous(), w).t(), ops.ew(_lib.EW_MUL, dy.contiguous(), xt)
+
+
+def test_emu_recording_refuses_a_node_that_runs_foreign_kernels():
+    """the dispatch watch is on for EVERY recording; a node body that executes a kernel that is not
+    ours is refused as a plan — that call's results are still right, later calls stay eager and right, nothing is replayed"""
+    import warnings
+    dev = use_emu()
+    plans.clear()
+    plans.enable(True)
+    plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0, refused=0)
+    try:
+        w = torch.nn.Parameter(torch.arange(12, dtype=torch.float32).reshape(4, 3) + 1.0)
+        outs = []
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for k in range(4):
+                x0 = (torch.arange(12, dtype=torch.float32).reshape(3, 4) * (k + 1)).requires_grad_(True)
+                x = x0 * 1.0                       # (a leaf that requires grad would count as a parameter: matched by identity)
+                w.grad = None
+                y = plans.apply(_NodeWithForeignKernel, x, w)
+                y.sum().backward()
+                assert torch.equal(y.detach(), x.detach().t() * w.detach()), k       # every call, replayed or not, is right
+                assert torch.equal(w.grad, x.detach().t())
+                outs.append(y)
+        assert plans.STATS["refused"] >= 1 and plans.STATS["replayed"] == 0 and plans.STATS["recorded"] == 0, plans.STATS
+        assert any("launch plan refused" in str(c.message) for c in caught)
+    finally:
+        plans.enable(False)
+        plans.clear()
+
+
+@pytest.mark.gpu
+def test_gpu_plans_follow_load_state_dict_and_mode_switch():
+    """(medium) replays skip FrozenBatchNorm2d.folded() and the weight-table key checks, so whatever rewrites
+    buffers / parameters behind a plan must invalidate it: load_state_dict with other FrozenBN statistics is followed by
+    the next steps (eager -> record -> replay again) and the replayed step equals an eager step of the modified model.
+    (high) switching the plane mode on a LIVE model (bf16x3p -> bf16x6p: two -> three planes per weight) rebuilds the weight
+    planes instead of writing a third plane past the two-plane buffers."""
+    from tests.backends import use_hip
+    dev = use_hip()
+    T, res = 8, 224
+    _lib.set_mma_mode("bf16x3p")
+    plans.clear()
+    plans.enable(True)
+    try:
+        ops.manual_seed(7)
+        model, criterion, wd = _build(dev)
+        clip = _clip(dev, T, res, 0)
+        for _ in range(3):
+            before = _step(model, criterion, wd, clip, T, res, dev)
+        replayed0 = plans.STATS["replayed"]
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        key = "vis_encoder.0.body.layer3.1.bn2.bias"
+        sd[key] = sd[key] + 0.5
+        epoch = plans.STATIC_EPOCH
+        model.load_state_dict(sd)
+        assert plans.STATIC_EPOCH > epoch
+        after = [_step(model, criterion, wd, clip, T, res, dev) for _ in range(3)]
+        assert plans.STATS["replayed"] > replayed0                     # the third step after the load is a replay again
+        plans.enable(False)
+        eager = _step(model, criterion, wd, clip, T, res, dev)
+        for k in eager[0]:
+            _same(after[0][0][k], eager[0][k], "first step after load_state_dict " + k, 2e-4)
+            _same(after[2][0][k], eager[0][k], "replayed step after load_state_dict " + k, 2e-4)
+        assert (eager[0]["pred_sted"] - before[0]["pred_sted"]).abs().max() > 1e-4     # the new statistics do matter
+        # ---- plane-mode switch on the same live model
+        _lib.set_mma_mode("bf16x6p")
+        six = _step(model, criterion, wd, clip, T, res, dev)
+        torch.cuda.synchronize()
+        for k in eager[0]:
+            _same(six[0][k], eager[0][k], "bf16x6p after bf16x3p on one model " + k, 2e-3)
+        body = model.vis_encoder[0].body
+        assert all(p.t.shape[0] == 3 for p in body._wpl_cache.fwd.values())
+        _lib.set_mma_mode("bf16x3p")
+        two = _step(model, criterion, wd, clip, T, res, dev)
+        for k in eager[0]:
+            _same(two[0][k], eager[0][k], "back to bf16x3p " + k, 2e-4)
+    finally:
+        plans.enable(False)
+        plans.clear()
+        _lib.set_mma_mode("f32")
