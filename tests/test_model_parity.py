@@ -651,9 +651,11 @@ def _print_gradient_report(tag, rows):
     e = sorted(r[1] for r in rows)
     outside = sum(1 for r in rows if r[0] > 1.0)
     worst = max(rows, key=lambda r: r[1])
+    gross = max(r[3] for r in rows)
+    strict = sum(1 for r in rows if r[1] > 3 * r[2] + GRAD_TOL)
     print(f"[gradient report] {tag}: {len(rows)} tensors, rel-L2 vs fp64 median {e[len(e) // 2]:.2e}, p90 "
           f"{e[int(0.9 * len(e))]:.2e}, max {e[-1]:.2e} ({worst[4]}; fp32 reference there {worst[2]:.2e}); "
-          f"{outside} outside 3 x e_ref + 1e-3")
+          f"{outside} outside the test's bound, {strict} outside 3 x e_ref + 1e-3; worst max-abs error / max-abs {gross:.2e}")
 
 
 @pytest.mark.gpu
@@ -754,11 +756,9 @@ def test_gpu_nonsquare_405x720_padded_clip_forward_backward():
     cross-attention, odd H (405 -> 203 -> 102 -> 51 -> 26 -> 13) and W % 32 != 0 in every conv.  Forward + loss +
     backward in the bench arithmetic vs the CPU oracle: outputs 1e-3 absolute, span bit-exact, calibrated gradients."""
     dev = use_hip()
-    # grad_slack 4: a padded margin is thousands of pixels with IDENTICAL activations (bias only), so a pre-activation
-    # that rounds to either side of zero there flips the ReLU of the whole margin at once — the conv gradients of a few
-    # layer3 blocks then sit at 0.4-1.3e-2 from exact where the un-padded clip (next test, slack 1) and the padded
-    # square clip pass the calibrated bound.  Outputs, span and the 30 loss terms are held to the usual bars.
-    _compare(_hip_case(dev, "NS8_ragged", mma=BENCH_MMA), Ref.fixture("NS8_ragged"), grad_slack=4.0)
+    # (round 3 compared with the oracle and needed grad_slack 4 here; against the reference's fixture the padded clip meets
+    # the plain calibrated bound: worst tensor 1.5e-2 where the fp32 reference is 3.0e-3 from its fp64 run, 1 of 626 outside)
+    _compare(_hip_case(dev, "NS8_ragged", mma=BENCH_MMA), Ref.fixture("NS8_ragged"))
 
 
 @pytest.mark.gpu
