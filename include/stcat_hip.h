@@ -32,7 +32,14 @@ const char* stcat_last_error(void);
 int stcat_set_mma_mode(int mode);
 int stcat_get_mma_mode(void);
 /*   4 = split-bf16 x3 with the backbone's activations, gradients and weights PRE-SPLIT into bf16 planes in HBM (the
- *       stcat_pl_* entry points below); every other GEMM of the path runs as mode 2 */
+ *       stcat_pl_* entry points below); every other GEMM of the path runs as mode 2
+ *   5 = three bf16 planes per backbone tensor (hi + mid + lo = the fp32 value exactly), six cross terms; others as mode 3
+ *   6 = (round 4, experimental) TWO IEEE-fp16 planes per backbone tensor (22 significand bits), three cross terms on
+ *       v_mfma_f32_32x32x16_f16; weight planes hold w * 2^wlog and gradient planes dy * 2^glog (fp16's range), undone in the
+ *       consuming epilogues; others as mode 3 */
+/* power-of-two operand scales of mode 6 (defaults 6 and 16: profiles/r04_plane_range_report.log); which: 0 weight, 1 gradient */
+int stcat_set_f16_scales(int weight_log2, int grad_log2);
+int stcat_get_f16_scale(int which);
 /* tuning/test hook: force the implicit-GEMM block tile (128x128, 128x64, 64x64; 0,0 = heuristic) */
 int stcat_debug_force_tile(int bm, int bn);
 /* stream-K scheduling of the split-bf16 forward GEMM (opt-in experiment): 1 whenever legal,

@@ -82,6 +82,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_spin": "is",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
+    "stcat_set_f16_scales": "ii",
+    "stcat_get_f16_scale": "i",
     # launch plans (csrc/launch_plan.h): P = host pointer, u = unsigned 64-bit, S = C string
     "stcat_plan_fn_index": "S",
     "stcat_plan_fn_nargs": "i",
@@ -140,8 +142,8 @@ def backend() -> str:
     return _backend
 
 
-MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "bf16x3p": 4, "bf16x6p": 5}
-PLANE_MODES = {"bf16x3p": 2, "bf16x6p": 3}   # mode -> bf16 planes per backbone tensor
+MMA_MODES = {"f32": 0, "bf16x3": 2, "bf16x6": 3, "bf16x3p": 4, "bf16x6p": 5, "f16x3p": 6}
+PLANE_MODES = {"bf16x3p": 2, "bf16x6p": 3, "f16x3p": 2}   # mode -> 16-bit planes per backbone tensor
 _mode_cache = None
 
 
@@ -151,7 +153,9 @@ def set_mma_mode(mode: str) -> None:
     arithmetic with the backbone's activations / gradients / weights kept PRE-SPLIT as bf16 hi/lo planes in HBM
     (csrc/igemm_pl.h: LDS-DMA staged 256-wide tiles); all other GEMMs run as 'bf16x3'.  'bf16x6p' is the fp32-class
     form of that layout: THREE bf16 planes per tensor (hi + mid + lo = the fp32 value exactly), six cross terms per
-    product; all other GEMMs run as 'bf16x6' and attention on the fp32 matrix pipe."""
+    product; all other GEMMs run as 'bf16x6' and attention on the fp32 matrix pipe.  'f16x3p' (round 4, experimental): TWO
+    fp16 planes per backbone tensor (22 significand bits, three products), weights / gradients scaled by powers of two
+    into fp16's range (`f16_grad_scale()`); everything outside the backbone as in 'bf16x6p'."""
     global _mode_cache
     call("stcat_set_mma_mode", MMA_MODES[mode])
     _mode_cache = mode
@@ -163,6 +167,12 @@ def get_mma_mode() -> str:
         code = load().stcat_get_mma_mode()
         _mode_cache = {v: k for k, v in MMA_MODES.items()}[code]
     return _mode_cache
+
+
+def f16_grad_scale() -> float:
+    """factor carried by every GRADIENT plane in mode f16x3p (1.0 in every other mode): tools / op tests that build
+    gradient planes themselves multiply by it; the product path scales where gradients enter the backbone (pl_act_bwd)"""
+    return float(2 ** load().stcat_get_f16_scale(1)) if get_mma_mode() == "f16x3p" else 1.0
 
 
 def plane_count() -> int:

@@ -57,12 +57,43 @@ struct PlParams {
   float* C2f;                           // second scaled output
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
   const float* wscale;                  // wgrad: optional per-row factor dW[m][:] *= wscale[m] (a FrozenBN scale folded out of dY)
+  float acc_mul;                        // the accumulator is multiplied by this before scale / bias (fwd, dgrad) or before
+                                        // the atomics (wgrad): 1, or 2^-k undoing the operand scales of mode f16x3p
   int stagger;                          // fwd kernel: phase stagger of the first-round workgroups, in 10 ns ticks per quarter
                                         // (0 = off); set by the launcher for many-round, epilogue-heavy launches
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
                                         // 2 = epilogue without global loads / stores
   IgemmGeom g;
 };
+
+// Element type of a plane.  The planes are 16-bit containers (`__bf16` in every signature); what the 16 bits MEAN is a
+// compile-time property of the kernel: bf16 (8 significand bits, fp32's range) or — mma mode f16x3p, round 4 — IEEE fp16
+// (11 significand bits: hi + lo = 22 bits in TWO planes, three products, on v_mfma_f32_32x32x16_f16; fp16's range is what
+// the per-class power-of-two scales of that mode are for: weights x 2^wlog, gradients x 2^glog, PlParams::acc_mul undoes them).
+template <bool F16> struct PlElt {
+  static __device__ __forceinline__ float up(__bf16 v) {
+    if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v); else return (float)v;
+  }
+  static __device__ __forceinline__ __bf16 down(float x) {
+    if constexpr (F16) {
+#ifndef STCAT_EMU
+      // The value to convert must be ONE fp32 number in a register: left to itself the compiler folds a preceding
+      // multiply into the conversion (v_fma_mix*: fp16 of the UNROUNDED product) for the stored plane while the
+      // subtraction that forms the next plane uses the rounded product — near a rounding midpoint the two disagree and
+      // the pair is off by one fp16 ulp (measured: the scaled second output of the data gradient, 2^-12 instead of 2^-23).
+      asm volatile("" : "+v"(x));
+#endif
+      return __builtin_bit_cast(__bf16, (_Float16)x);
+    } else {
+      return (__bf16)x;
+    }
+  }
+};
+template <bool F16>
+static __device__ __forceinline__ f32x16 stcat_pl_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return STCAT_MFMA_F16_32x32x16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+  else return STCAT_MFMA_BF16_32x32x16(a, b, c);
+}
 
 static __device__ __forceinline__ void stcat_split8(const float (&v)[8], bf16x8& h, bf16x8& l) {
   STCAT_UNROLL
@@ -84,25 +115,25 @@ static __device__ __forceinline__ const __bf16* stcat_plane(const __bf16* h, con
 static __device__ __forceinline__ __bf16* stcat_plane(__bf16* h, __bf16* l, int i) {
   return i == 0 ? h : (i == 1 ? l : l + (l - h));
 }
-template <int NP>
+template <int NP, bool F16 = false>
 static __device__ __forceinline__ void stcat_split8n(const float (&v)[8], bf16x8 (&o)[NP]) {
   STCAT_UNROLL
   for (int e = 0; e < 8; ++e) {
     float r = v[e];
     STCAT_UNROLL
     for (int i = 0; i < NP; ++i) {
-      const __bf16 q = (__bf16)r;
+      const __bf16 q = PlElt<F16>::down(r);
       o[i][e] = q;
-      r -= (float)q;
+      r -= PlElt<F16>::up(q);
     }
   }
 }
 // value of element e of a plane set held in registers (small pieces first: the sum is exact for NP = 3)
-template <int NP>
+template <int NP, bool F16 = false>
 static __device__ __forceinline__ float stcat_join1(const bf16x8 (&o)[NP], int e) {
-  float r = (float)o[NP - 1][e];
+  float r = PlElt<F16>::up(o[NP - 1][e]);
   STCAT_UNROLL
-  for (int i = NP - 2; i >= 0; --i) r += (float)o[i][e];
+  for (int i = NP - 2; i >= 0; --i) r += PlElt<F16>::up(o[i][e]);
   return r;
 }
 // cross terms of the split contraction, smallest first: (index of the A piece, index of the B piece)
@@ -148,7 +179,7 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
     for (int tm = 0; tm < TM; ++tm) {                                                                   \
       STCAT_UNROLL                                                                                      \
       for (int tn = 0; tn < TN; ++tn)                                                                   \
-        acc[tm][tn] = STCAT_MFMA_BF16_32x32x16(F.a[PlProd<NP>::a(pr_)][tm], F.b[PlProd<NP>::b(pr_)][tn], acc[tm][tn]); \
+        acc[tm][tn] = stcat_pl_mfma<F16>(F.a[PlProd<NP>::a(pr_)][tm], F.b[PlProd<NP>::b(pr_)][tn], acc[tm][tn]); \
     }                                                                                                   \
   }
 
@@ -182,13 +213,14 @@ static __device__ __forceinline__ void stcat_join8(const __bf16* hp, const __bf1
 // forward / data gradient:  C[m][n] = epi( sum_r Agather[m][r] * B[n][r] ),  r = (tap, c), c fastest
 // 8 waves as WM x WN, wave tile (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32 x 32.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool F32 = false, int NP = 2, int NW = 8>
+template <int BM, int BN, int WM, int WN, bool F32 = false, int NP = 2, int NW = 8, bool F16 = false>
 __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   // NW = 8: one workgroup per CU (two waves per SIMD).  NW = 4 (128 x 64 tile, three planes: 74 KB of LDS): TWO workgroups
   // per CU with the same two waves per SIMD — their phases drift apart, so one's epilogue / first loads (HBM) run under
   // the other's MFMAs: the form for the K <= 512 1x1 convolutions, whose epilogue traffic is as long as their K loop
   static_assert(WM * WN == NW, "NW waves");
   static_assert(!(F32 && NP != 2), "the exact-fp32 form keeps the two-plane LDS layout");
+  static_assert(!(F16 && (F32 || NP != 2)), "fp16 planes come in pairs");
   constexpr int BK = 32, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NPL = F32 ? 1 : NP;                              // planes actually staged
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;            // bytes: rows x 64 B
@@ -422,7 +454,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   float sc[8], bi[8], ms[8], s2[8];
   STCAT_UNROLL
   for (int e = 0; e < 8; ++e) {
-    sc[e] = p.scale ? p.scale[n + e] : 1.f;
+    sc[e] = (p.scale ? p.scale[n + e] : 1.f) * p.acc_mul;      // (acc_mul: 1, or the power of two that undoes mode f16x3p's operand scale)
     bi[e] = p.bias ? p.bias[n + e] : 0.f;
     ms[e] = p.mscale ? p.mscale[n + e] : 1.f;
     s2[e] = p.c2scale ? p.c2scale[n + e] : 1.f;
@@ -452,7 +484,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
         for (int e = 0; e < 8; ++e) x[e] = x[e] * sc[e] + bi[e];
         if (p.Rh) {
           STCAT_UNROLL
-          for (int e = 0; e < 8; ++e) x[e] += stcat_join1<NP>(cur.r[ps], e);
+          for (int e = 0; e < 8; ++e) x[e] += stcat_join1<NP, F16>(cur.r[ps], e);
         } else if (F32 && p.Rf) {
           const float4 r0 = stcat_ld4(p.Rf + (long)m * p.ldr + n), r1 = stcat_ld4(p.Rf + (long)m * p.ldr + n + 4);
           x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
@@ -469,7 +501,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
           // the sign of y is the sign of its leading plane (the residual planes never flip it; y == 0 <=> p0 == 0)
           const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(p.Yh + (long)m * p.ldc + n);
           STCAT_UNROLL
-          for (int e = 0; e < 8; ++e) x[e] = (float)y0[e] > 0.f ? x[e] * ms[e] : 0.f;
+          for (int e = 0; e < 8; ++e) x[e] = PlElt<F16>::up(y0[e]) > 0.f ? x[e] * ms[e] : 0.f;
         } else if (F32 && p.Yf) {
           const float4 y0 = stcat_ld4(p.Yf + (long)m * p.ldc + n), y1 = stcat_ld4(p.Yf + (long)m * p.ldc + n + 4);
           const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -484,7 +516,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
         }
         if (p.Ch && !((p.debug & 64) && x[0] != 12345.f)) {     // (debug 64: no plane stores)
           bf16x8 o8[NP];
-          stcat_split8n<NP>(x, o8);
+          stcat_split8n<NP, F16>(x, o8);
           STCAT_UNROLL
           for (int pi = 0; pi < NP; ++pi) STCAT_STORE_STREAM(reinterpret_cast<bf16x8*>(Cp[pi] + (long)m * p.ldc + n), o8[pi]);
         }
@@ -500,7 +532,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] *= s2[e];
           bf16x8 o8[NP];
-          stcat_split8n<NP>(x, o8);
+          stcat_split8n<NP, F16>(x, o8);
           STCAT_UNROLL
           for (int pi = 0; pi < NP; ++pi) *reinterpret_cast<bf16x8*>(C2p[pi] + (long)m * p.ldc + n) = o8[pi];
         }
@@ -518,7 +550,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
 // bytes; its 64-byte segments are XOR-ed with (k & 3) inside each 256-byte group, so the four k-rows that one
 // transposing read touches sit in four different bank quarters.
 // ---------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NP = 2>
+template <int BM, int BN, int WM, int WN, int NP = 2, bool F16 = false>
 __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(BM % 128 == 0 && BN % 128 == 0, "a k-row is a whole number of 256-byte groups");
@@ -679,7 +711,7 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       STCAT_UNROLL
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float v_ = p.wscale ? acc[tm][tn][r] * p.wscale[m] : acc[tm][tn][r];
+        const float v_ = (p.wscale ? acc[tm][tn][r] * p.wscale[m] : acc[tm][tn][r]) * p.acc_mul;
         if (!((p.debug & 1) && v_ != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], v_);
       }
     }
@@ -691,6 +723,13 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
 // ---------------------------------------------------------------------------------------------------
 // split 8 values into np (2 or 3) planes and store them at element offset `at` of each plane
 static __device__ __forceinline__ void stcat_store_planes(const float (&v)[8], __bf16* h, __bf16* l, long at, int np) {
+  if (np >> 8) {                           // fp16 hi + lo (mode f16x3p): np = 2 | 0x100
+    bf16x8 o[2];
+    stcat_split8n<2, true>(v, o);
+    *reinterpret_cast<bf16x8*>(h + at) = o[0];
+    *reinterpret_cast<bf16x8*>(l + at) = o[1];
+    return;
+  }
   if (np == 3) {
     bf16x8 o[3];
     stcat_split8n<3>(v, o);
@@ -705,6 +744,12 @@ static __device__ __forceinline__ void stcat_store_planes(const float (&v)[8], _
   }
 }
 static __device__ __forceinline__ void stcat_load_planes(const __bf16* h, const __bf16* l, long at, int np, float (&v)[8]) {
+  if (np >> 8) {
+    const bf16x8 o[2] = {*reinterpret_cast<const bf16x8*>(h + at), *reinterpret_cast<const bf16x8*>(l + at)};
+    STCAT_UNROLL
+    for (int e = 0; e < 8; ++e) v[e] = stcat_join1<2, true>(o, e);
+    return;
+  }
   stcat_join8(h + at, l + at, v);
   if (np == 3) {
     const bf16x8 t = *reinterpret_cast<const bf16x8*>(stcat_plane(h, l, 2) + at);
@@ -751,7 +796,8 @@ struct PlEwParams {
   __bf16* Gh; __bf16* Gl; __bf16* Rh; __bf16* Rl;
   float* of;
   long n8; int C; int mode; int relu;
-  int np;   // planes per set: 2 or 3
+  int np;   // planes per set: 2 or 3 (| 0x100: fp16 elements)
+  float gmul;   // mode 1 (gradient entering the plane domain): factor on dz — 1, or mode f16x3p's loss scale 2^glog
 };
 __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n8; i += (long)gridDim.x * blockDim.x) {
@@ -772,6 +818,10 @@ __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
       const float yy[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       STCAT_UNROLL
       for (int e = 0; e < 8; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
+    }
+    if (p.mode == 1 && p.gmul != 1.f) {
+      STCAT_UNROLL
+      for (int e = 0; e < 8; ++e) v[e] *= p.gmul;
     }
     if (p.Rh) stcat_store_planes(v, p.Rh, p.Rl, i * 8, p.np);
     if (p.Gh) {
@@ -799,6 +849,12 @@ struct WplEntry {
   int pad_;
 };
 static __device__ __forceinline__ void stcat_store_planes1(float x, __bf16* h, __bf16* l, long idx, int np) {
+  if (np >> 8) {
+    const __bf16 q0 = PlElt<true>::down(x);
+    h[idx] = q0;
+    l[idx] = PlElt<true>::down(x - PlElt<true>::up(q0));
+    return;
+  }
   const __bf16 q0 = (__bf16)x;
   h[idx] = q0;
   const float r1 = x - (float)q0;
@@ -806,7 +862,7 @@ static __device__ __forceinline__ void stcat_store_planes1(float x, __bf16* h, _
   l[idx] = q1;
   if (np == 3) stcat_plane(h, l, 2)[idx] = (__bf16)(r1 - (float)q1);
 }
-__global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry* tab, int n, int np) {
+__global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry* tab, int n, int np, float wmul) {
   __shared__ float tile[32][33];
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -823,7 +879,7 @@ __global__ void __launch_bounds__(256) weight_planes_multi_kernel(const WplEntry
     float x = 0.f;
     if (co < e.Cout && ci < e.Cin) {
       const long idx = ((long)co * e.taps + tap) * e.Cin + ci;
-      x = e.w[idx];
+      x = e.w[idx] * wmul;                 // (wmul: 1, or mode f16x3p's weight scale 2^wlog)
       stcat_store_planes1(x, e.wh, e.wl, idx, np);
     }
     tile[r][tx] = (e.tscale && co < e.Cout) ? x * e.tscale[co] : x;

@@ -80,7 +80,10 @@ void pick_tile(int M, int N, int& BM, int& BN) {
 // bf16 planes (igemm_pl.h; every other GEMM of the path runs as mode 2)   (stcat_set_mma_mode)
 int g_mma_mode_raw = 0;
 int g_mma_mode = 0;  // what the fp32-tensor kernels see: mode 4 -> 2, mode 5 -> 3
-int g_pl_np = 2;     // planes per tensor of the plane-format entry points: 2 (mode 4) or 3 (mode 5)
+int g_pl_np = 2;     // planes per tensor of the plane-format entry points: 2 (modes 4, 6) or 3 (mode 5)
+int g_pl_f16 = 0;    // mode 6 (f16x3p): the two planes hold IEEE fp16 (22 significand bits), three products on the f16 MFMA
+int g_f16_wlog = 6, g_f16_glog = 16;   // its operand scales: weight planes hold w * 2^wlog, gradient planes dy * 2^glog
+inline int pl_np_arg() { return g_pl_np | (g_pl_f16 ? 0x100 : 0); }   // what the element-wise plane kernels take as `np`
 
 #define STCAT_TILE_SWITCH(KERNEL, GRID)                                                        \
   if (BM == 128 && BN == 128) {                                                                \
@@ -315,6 +318,19 @@ int pl_prepare(K kernel, int lds_bytes) {
     if (int rc_ = pl_prepare(KERNEL<BM_, BN_, WM_, WN_>, lds_)) return rc_;                            \
     STCAT_LAUNCH((KERNEL<BM_, BN_, WM_, WN_>), GRID, dim3(512), lds_, st, p);                          \
   }
+// fp16-plane (mode 6) instantiations of the two-plane tiles
+#define STCAT_PLH_FWD(BM_, BN_, WM_, WN_, GRID)                                                                 \
+  {                                                                                                            \
+    constexpr int lds_ = 4 * (BM_ + BN_) * 64;                                                                 \
+    if (int rc_ = pl_prepare(igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 2, 8, true>, lds_)) return rc_;    \
+    STCAT_LAUNCH((igemm_pl_fwd_kernel<BM_, BN_, WM_, WN_, false, 2, 8, true>), GRID, dim3(512), lds_, st, p);  \
+  }
+#define STCAT_PLH_WGRAD(BM_, BN_, WM_, WN_, GRID)                                                      \
+  {                                                                                                    \
+    constexpr int lds_ = 4 * (BM_ + BN_) * 64;                                                         \
+    if (int rc_ = pl_prepare(igemm_pl_wgrad_kernel<BM_, BN_, WM_, WN_, 2, true>, lds_)) return rc_;    \
+    STCAT_LAUNCH((igemm_pl_wgrad_kernel<BM_, BN_, WM_, WN_, 2, true>), GRID, dim3(512), lds_, st, p);  \
+  }
 // three-plane (mode 5) instantiations: 6 x (BM + BN) x 64 bytes of LDS for the two stages
 #define STCAT_PL3_FWD_NW(BM_, BN_, WM_, WN_, NW_, GRID)                                                         \
   {                                                                                                            \
@@ -396,6 +412,8 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   PlParams p = p_;
   p.debug = g_pl_debug & 0xff;
   p.stagger = (g_pl_debug & 8) ? (g_pl_debug >> 8) : 0;
+  // mode f16x3p: the B operand (weight planes, plain or transposed) carries 2^wlog; gradient planes keep their 2^glog
+  p.acc_mul = g_pl_f16 ? ldexpf(1.f, -g_f16_wlog) : 1.f;
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
@@ -413,6 +431,17 @@ int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
       case 3: STCAT_PL3_FWD(128, 128, 2, 4, grid) break;
       case 6: STCAT_PL3_FWD_NW(128, 64, 2, 2, 4, grid) break;
       default: STCAT_PL3_FWD(256, 64, 8, 1, grid) break;
+    }
+    return launch_status();
+  }
+  if (g_pl_f16) {
+    switch (ti) {
+      case 0: STCAT_PLH_FWD(256, 256, 2, 4, grid) break;
+      case 1: STCAT_PLH_FWD(256, 128, 4, 2, grid) break;
+      case 2: STCAT_PLH_FWD(128, 256, 2, 4, grid) break;
+      case 3: STCAT_PLH_FWD(128, 128, 2, 4, grid) break;
+      case 5: STCAT_PLH_FWD(224, 256, 1, 8, grid) break;
+      default: STCAT_PLH_FWD(256, 64, 8, 1, grid) break;
     }
     return launch_status();
   }
@@ -442,7 +471,7 @@ int launch_pl_fwd_f32(const IgemmParams& s, hipStream_t st) {
   PlParams p = {};
   p.Ah = reinterpret_cast<const __bf16*>(s.A); p.Bh = reinterpret_cast<const __bf16*>(s.B);
   p.Cf = s.C; p.scale = s.scale; p.bias = s.bias; p.Rf = s.res; p.Yf = s.mask; p.mscale = s.mscale;
-  p.C2f = s.C2; p.c2scale = s.c2scale;
+  p.C2f = s.C2; p.c2scale = s.c2scale; p.acc_mul = 1.f;
   p.M = s.M; p.N = s.N; p.K = 2 * s.K; p.ldb = 2 * s.ldb; p.ldc = s.ldc; p.ldr = s.ldr; p.relu = s.relu;
   p.a_bytes = s.a_bytes; p.b_bytes = s.b_bytes;
   p.b_tap_stride = s.b_tap_stride / 2;          // bytes -> half-float units
@@ -507,7 +536,15 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   chunk = ((chunk + 31) / 32) * 32;
   nsplit = cdiv(red, chunk);
   p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk; p.debug = g_pl_debug;
+  p.acc_mul = g_pl_f16 ? ldexpf(1.f, -g_f16_glog) : 1.f;     // mode f16x3p: dY planes hold dy * 2^glog, X planes are unscaled
   const dim3 grid(tiles, 1, nsplit);
+  if (g_pl_f16) {
+    if (BM == 256 && BN == 256) STCAT_PLH_WGRAD(256, 256, 2, 4, grid)
+    else if (BM == 256) STCAT_PLH_WGRAD(256, 128, 4, 2, grid)
+    else if (BN == 256) STCAT_PLH_WGRAD(128, 256, 2, 4, grid)
+    else STCAT_PLH_WGRAD(128, 128, 2, 4, grid)
+    return launch_status();
+  }
   if (g_pl_np == 3) {
     if (BM == 256) STCAT_PL3_WGRAD(256, 128, 4, 2, grid)
     else if (BN == 256) STCAT_PL3_WGRAD(128, 256, 2, 4, grid)
@@ -537,14 +574,23 @@ extern "C" {
 
 int stcat_version(void) { return 100; }
 int stcat_set_mma_mode(int mode) {
-  if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5)
-    return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3), 3 (bf16x6), 4 (bf16x3 on two bf16 planes) or 5 (bf16x6 on three)");
+  if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6)
+    return fail("set_mma_mode: mode must be 0 (f32), 2 (bf16x3), 3 (bf16x6), 4 (bf16x3 on two bf16 planes), 5 (bf16x6 on three) "
+                "or 6 (f16x3 on two fp16 planes)");
   g_mma_mode_raw = mode;
-  g_mma_mode = mode == 4 ? 2 : (mode == 5 ? 3 : mode);
+  g_mma_mode = mode == 4 ? 2 : ((mode == 5 || mode == 6) ? 3 : mode);   // (modes 5 / 6: every other GEMM as bf16x6)
   g_pl_np = mode == 5 ? 3 : 2;
+  g_pl_f16 = mode == 6 ? 1 : 0;
   return 0;
 }
 int stcat_get_mma_mode(void) { return g_mma_mode_raw; }
+int stcat_set_f16_scales(int weight_log2, int grad_log2) {
+  if (weight_log2 < 0 || weight_log2 > 14 || grad_log2 < 0 || grad_log2 > 30) return fail("set_f16_scales: exponents out of range");
+  g_f16_wlog = weight_log2;
+  g_f16_glog = grad_log2;
+  return 0;
+}
+int stcat_get_f16_scale(int which) { return which == 0 ? g_f16_wlog : g_f16_glog; }
 
 int stcat_debug_force_tile(int bm, int bn) {
   const bool ok = (bm == 0 && bn == 0) || (bm == 128 && bn == 128) || (bm == 128 && bn == 64) || (bm == 64 && bn == 64) ||
@@ -1173,14 +1219,15 @@ int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int 
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long total = (long)n * OH * OW * (C / 8);
   STCAT_LAUNCH(maxpool3x3s2_pl_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
-               (__bf16*)yh, (__bf16*)yl, n, H, W, C, OH, OW, g_pl_np);
+               (__bf16*)yh, (__bf16*)yl, n, H, W, C, OH, OW, pl_np_arg());
   return launch_status();
 }
 
 static int pl_ew(PlEwParams p, long n, void* stream) {
   if (n <= 0 || n % 8 != 0) return fail("plane element-wise: n = %ld must be a positive multiple of 8", n);
   p.n8 = n / 8;
-  p.np = g_pl_np;
+  p.np = pl_np_arg();
+  p.gmul = (g_pl_f16 && p.mode == 1) ? ldexpf(1.f, g_f16_glog) : 1.f;   // gradients enter the fp16 plane domain scaled
   STCAT_LAUNCH(planes_ew_kernel, dim3(grid_for(p.n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
@@ -1219,7 +1266,7 @@ int stcat_weight_planes_entry_bytes(void) { return (int)sizeof(WplEntry); }
 int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks, void* stream) {
   if (n_entries <= 0 || total_blocks <= 0) return fail("weight_planes_multi: empty table");
   STCAT_LAUNCH(weight_planes_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WplEntry*)table,
-               n_entries, g_pl_np);
+               n_entries, pl_np_arg(), g_pl_f16 ? ldexpf(1.f, g_f16_wlog) : 1.f);
   return launch_status();
 }
 

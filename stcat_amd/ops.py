@@ -878,7 +878,7 @@ class MhaSelfFn(Function):
         # (mode bf16x6p is fp32-class end to end: its attention runs on the fp32 matrix pipe as well)
         # rows longer than 256 tokens (non-square clips) train through the fp32 long-row kernels in every mode: the
         # bf16-pipe backward keeps a whole row's tiles in LDS and is built for S <= 256
-        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p")
+        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p", "f16x3p")
                   and (S <= 256 or not any(ctx.needs_input_grad[:3])))
         if ctx.bs:
             keep = any(ctx.needs_input_grad[:3])
@@ -1439,7 +1439,7 @@ class WeightPlanes:
         # two-plane buffers, the three-plane kernels would write / read a third plane past their end)
         want_tr = bool(transposed) or bool(self.tr)
         key = (tuple(w.data_ptr() for w in weights), want_tr,
-               tuple(0 if t is None else t.data_ptr() for t in tscales), L.plane_count())
+               tuple(0 if t is None else t.data_ptr() for t in tscales), L.plane_count(), L.get_mma_mode())
         if key != self.key:
             if self.key is not None:      # a weight moved / the plane mode changed: launch plans hold the old table
                 from . import plans

@@ -261,6 +261,27 @@ static inline f32x16 emu_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_f16: the same lane mapping on fp16 operands
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+static inline f32x16 emu_mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+  emu::WaveState& w = emu::wave();
+  float (*sa)[8] = w.xa8;
+  float (*sb)[8] = w.xb8;
+  const int l = emu::lane();
+  for (int j = 0; j < 8; ++j) { sa[l][j] = (float)a[j]; sb[l][j] = (float)b[j]; }
+  emu::wave_sync();
+  const int col = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h)
+      for (int j = 0; j < 8; ++j) acc = fmaf(sa[i + 32 * h][j], sb[col + 32 * h][j], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);

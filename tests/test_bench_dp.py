@@ -63,6 +63,8 @@ def test_bench_default_line_over_the_rccl_path_single_rank():
     assert d["config"]["loss_plan"].startswith("rebuilt inside every timed step")
     assert d["throughput_mode"]["mma"].startswith("3 bf16 cross terms") and d["throughput_mode"]["steps"] == 10
     assert d["exact_f32_mode"]["steps"] == 10 and d["exact_f32_mode"]["warmup"] == 3
+    # round 4: the experimental 22-bit mode (two fp16 planes) is timed beside the headline, never in its place
+    assert d["near_f32_mode"]["mma"].startswith("3 fp16 cross terms") and d["near_f32_mode"]["steps"] == 10
     assert d["kernels"]["stcat_weight_planes_multi"]["launches"] == 1
     assert d["roofline"]["mfma_flops_per_algorithmic_flop"] == 6
     assert d["roofline"]["isolated_avg_launch_ms"] > 0 and 0 < d["roofline"]["frac"] < 1

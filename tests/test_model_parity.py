@@ -597,7 +597,7 @@ def test_gpu_c1_forward_backward(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6", "bf16x3p", "bf16x6p"])
+@pytest.mark.parametrize("mma", ["bf16x3", "bf16x6", "bf16x3p", "bf16x6p", "f16x3p"])
 def test_gpu_c1_split_bf16_modes(mma):
     """The split-bf16 GEMM modes must meet the same bars as the fp32-MFMA mode."""
     dev = use_hip()
@@ -626,6 +626,13 @@ def test_emu_tiny_clip_bf16x6_planes():
 def test_emu_tiny_clip_bf16x6_planes_full_depth():
     dev = use_emu()
     _compare(_run_hip(dev, 2, 64, 3, mma="bf16x6p"), Ref.oracle(2, 64, 3))
+
+
+def test_emu_tiny_clip_f16x3_planes():
+    """mma mode f16x3p (round 4, experimental): two fp16 planes per backbone tensor (22 significand bits, three products),
+    weight / gradient planes scaled by powers of two into fp16's range — held to the calibrated fp32-class gradient bound"""
+    dev = use_emu()
+    _compare(_run_hip(dev, 2, 64, 3, mma="f16x3p", blocks=SMALL_NET), Ref.oracle(2, 64, 3, blocks=SMALL_NET))
 
 
 def test_emu_tiny_clip_bf16x3():
@@ -734,6 +741,26 @@ def test_gpu_c1_replayed_bench_step():
     """the same at C1 (T=8, 224 x 224), where a step is almost pure launch sequence"""
     dev = use_hip()
     _compare(_run_bench_step(dev, "C1", BENCH_MMA), Ref.fixture("C1"))
+
+
+@pytest.mark.gpu
+def test_gpu_c3_full_size_forward_backward_fp16_planes():
+    """mode f16x3p (round 4, experimental: two fp16 planes = 22 significand bits, three products, power-of-two operand
+    scales) at the benchmark size against the reference fixture, held to the CALIBRATED fp32-class gradient bound — the
+    bound `bf16x6p` and the exact-fp32 mode are held to, not the 16-bit modes' family caps"""
+    dev = use_hip()
+    _compare(_hip_case(dev, "C3", mma="f16x3p"), Ref.fixture("C3"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["C2", "C5", "SQ8_ragged", "NS8", "NS8_ragged"])
+def test_gpu_fp16_planes_other_cases(case):
+    """mode f16x3p on the other reference fixtures: HC-STVG-shaped forward (C2), the long clip (C5: T=128, L=40), padded and
+    non-square clips with backward — the ranges that decide whether fp16 planes overflow or go subnormal differ from clip to
+    clip, the scales are constants: same bars as the default arithmetic, calibrated gradient bound"""
+    dev = use_hip()
+    bwd = synth.MODEL_CASES[case][4]
+    _compare(_hip_case(dev, case, mma="f16x3p"), Ref.fixture(case), with_backward=bwd)
 
 
 # ---- non-square and padded clips (VERDICT r02 #4) ---------------------------------------------------------------------

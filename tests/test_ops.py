@@ -159,16 +159,25 @@ def _pl_conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=-1, w
     six-term products (fp32-class: held to a 10x tighter bound than the 16-bit mode)"""
     old_mode = L.get_mma_mode()
     L.set_mma_mode(mode)
+    if mode == "f16x3p":       # the test's gradients are O(1), not the 2^-15 of a training step: a loss scale of 2^2, not 2^16
+        L.call("stcat_set_f16_scales", 6, 2)
     try:
         _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgrad, mode)
     finally:
+        L.call("stcat_set_f16_scales", 6, 16)
         L.set_mma_mode(old_mode)
 
 
 def _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgrad, mode):
     exact = mode == "bf16x6p"
-    TOL = 2e-5 if exact else 2e-4
-    RT = 0.0 if exact else 2e-5           # split / join round trip
+    f16 = mode == "f16x3p"                # two fp16 planes: 22 significand bits (round trip 2^-23), three products
+    TOL = 2e-5 if (exact or f16) else 2e-4
+    RT = 0.0 if exact else (2e-6 if f16 else 2e-5)           # split / join round trip
+    # mode f16x3p keeps gradient planes scaled by 2^glog and weight planes by 2^wlog (fp16's range): joined planes are
+    # compared after undoing the power of two (exact)
+    GS = L.f16_grad_scale()
+    WS = float(2 ** L.load().stcat_get_f16_scale(0)) if f16 else 1.0
+    unG = (lambda t: t / GS) if f16 else (lambda t: t)
     x = rnd(n, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
     scale, bias = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
@@ -191,8 +200,8 @@ def _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgra
     cache = ops.WeightPlanes()
     wp, wt = cache.refresh([wd], transposed=True)
     wp, wt = wp[wd.data_ptr()], wt[wd.data_ptr()]
-    close(ops.pl_join(wp), wd, RT, "weight planes")
-    close(ops.pl_join(wt), wd.view(Cout, k * k, Cin).permute(1, 2, 0), RT, "transposed weight planes")
+    close(ops.pl_join(wp) / WS, wd, RT, "weight planes")
+    close(ops.pl_join(wt) / WS, wd.view(Cout, k * k, Cin).permute(1, 2, 0), RT, "transposed weight planes")
     L.call("stcat_debug_force_pl_tile", tile)
     try:
         yp, yf = ops.pl_conv_fwd_raw(xp, wp, sd, bd, rp, stride, pad, relu, planes_out=True, f32_out=True, want_mask=True)
@@ -224,21 +233,21 @@ def _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgra
     tag = f"plane conv [{mode}] {k}x{k}/{stride} {Cin}->{Cout} {H}x{W} tile{tile}"
     close(yf.permute(0, 3, 1, 2), ref, TOL, tag + " fwd (fp32 out)")
     close(ops.pl_join(yp), yf, RT, tag + " fwd (planes out)")
-    close(ops.pl_join(dx).permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
+    close(unG(ops.pl_join(dx)).permute(0, 3, 1, 2), xr.grad, TOL, tag + " dgrad")
     ref3 = xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0) * msc.cpu()
-    close(ops.pl_join(dx3), ref3, TOL, tag + " dgrad+fused relu/bn backward")
+    close(unG(ops.pl_join(dx3)), ref3, TOL, tag + " dgrad+fused relu/bn backward")
     ref4 = 2 * xr.grad.permute(0, 2, 3, 1) * (ymask.cpu() > 0)
-    close(ops.pl_join(dx4), ref4, TOL, tag + " dgrad boundary dz")
-    close(ops.pl_join(dx5), ref4 * msc.cpu(), TOL, tag + " dgrad boundary dz*scale")
-    close(ops.pl_join(gs), ops.pl_join(G).cpu() * msc[:1].cpu(), 2e-5, tag + " plane scale")
-    close(ops.pl_join(dx_fold), ops.pl_join(dx_ref), 5e-5, tag + " dgrad with the scale folded into the weight planes")
+    close(unG(ops.pl_join(dx4)), ref4, TOL, tag + " dgrad boundary dz")
+    close(unG(ops.pl_join(dx5)), ref4 * msc.cpu(), TOL, tag + " dgrad boundary dz*scale")
+    close(unG(ops.pl_join(gs)), unG(ops.pl_join(G)).cpu() * msc[:1].cpu(), 2e-5, tag + " plane scale")
+    close(unG(ops.pl_join(dx_fold)), unG(ops.pl_join(dx_ref)), 5e-5, tag + " dgrad with the scale folded into the weight planes")
     if wgrad:
         close(dw_fold, dw_sref, 5e-5, tag + " wgrad with the scale folded into the epilogue")
     if wgrad:
         close(dw.permute(0, 3, 1, 2), wr.grad, TOL, tag + " wgrad")
     if res:
         mask = (ref > 0).float() if relu else torch.ones_like(ref)
-        close(ops.pl_join(dres).permute(0, 3, 1, 2), gy * mask, RT, tag + " dres")
+        close(unG(ops.pl_join(dres)).permute(0, 3, 1, 2), gy * mask, RT, tag + " dres")
 
 
 @both
@@ -261,13 +270,19 @@ def _pl_conv(dev, big):
     _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=3, mode="bf16x6p")
     _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2, mode="bf16x6p")
     _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0, mode="bf16x6p")
+    # fp16-plane mode (f16x3p, round 4): every two-plane tile shape, the parity-class data gradient, residual planes, wgrad
+    _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=4, wgrad=False, mode="f16x3p")
+    _pl_conv_case(dev, 1, 9, 7, 128, 128, 1, 2, 0, relu=False, res=False, tile=1, mode="f16x3p")
+    _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=3, mode="f16x3p")
+    _pl_conv_case(dev, 2, 5, 5, 128, 256, 1, 1, 0, relu=True, res=True, tile=2, mode="f16x3p")
+    _pl_conv_case(dev, 1, 6, 5, 256, 256, 3, 1, 1, relu=True, res=False, tile=0, mode="f16x3p")
     # tile 6: 128 x 64 with FOUR waves (two workgroups per CU; the K <= 512 1x1 convolutions of mode bf16x6p): residual,
     # ragged tail, the parity-class data gradient, 3x3 taps
     _pl_conv_case(dev, 2, 9, 7, 128, 128, 1, 1, 0, relu=True, res=True, tile=6, mode="bf16x6p")
     _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=6, mode="bf16x6p")
     _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=6, wgrad=False, mode="bf16x6p")
     if big:
-        for m3 in ("bf16x6p",):
+        for m3 in ("bf16x6p", "f16x3p"):
             _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, mode=m3)
             _pl_conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False, mode=m3)
             _pl_conv_case(dev, 4, 28, 28, 512, 1024, 1, 2, 0, relu=False, res=False, mode=m3)
