@@ -963,12 +963,15 @@ def test_gpu_loss_trajectory_of_the_modes():
     again = _trajectory(dev, "f32", steps, T, res, L, lr)
     x6 = _trajectory(dev, BENCH_MMA, steps, T, res, L, lr)
     x3 = _trajectory(dev, THROUGHPUT_MMA, steps, T, res, L, lr)
+    h3 = _trajectory(dev, "f16x3p", steps, T, res, L, lr)        # round 4: two fp16 planes, held to the fp32-class bar
     rel = lambda a, b: max(abs(p - q) / max(1.0, abs(q)) for p, q in zip(a, b))   # noqa: E731
     noise = rel(again, ref)
     print(f"loss trajectories: f32 {ref}\n  f32 again (noise {noise:.2e})\n  bf16x6p {x6} (dev {rel(x6, ref):.2e})\n"
           f"  bf16x3p {x3} (dev {rel(x3, ref):.2e})")
     assert all(map(lambda v: v == v and abs(v) < 1e6, ref + x6 + x3))
     assert rel(x6, ref) <= max(2e-3, 5 * noise), (x6, ref)
+    print(f"  f16x3p {h3} (dev {rel(h3, ref):.2e})")
+    assert all(map(lambda v: v == v and abs(v) < 1e6, h3)) and rel(h3, ref) <= max(2e-3, 5 * noise), (h3, ref)
     assert rel(x3, ref) <= max(1e-2, 10 * noise), (x3, ref)
     for tr in (ref, x6, x3):            # same clip, six optimizer steps later: the loss went down
         assert tr[6] < tr[0] and tr[7] < tr[1], tr

@@ -42,3 +42,5 @@ python tools/pmc_traffic.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG > $O/hbm_traffic.jso
 python tools/pmc_mfma_util.py /tmp/pmc_m_$TAG > $O/mfma_util.json
 python tools/timeline.py /tmp/tl_$TAG > $O/timeline.log
 head -c 600 $O/mfma_util.json; echo; head -c 500 $O/hbm_traffic.json; echo; head -5 $O/timeline.log; head -8 $O/bench_kernel_stats.csv | cut -c1-160
+# per-tensor gradient error of the two plane arithmetics against the oracle's fp64 run at the benchmark size (full tensors; ~5 min of host time)
+timeout 1200 python tools/grad_error_report.py --config C3 --modes f16x3p,bf16x6p --out $O/grad_error_C3_f16x3p_bf16x6p.json > $O/grad_error.log 2>&1; grep -E "^==|backbone|ground_|input_proj" $O/grad_error.log | cut -c1-200 | head -30
