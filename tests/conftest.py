@@ -54,6 +54,22 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=rank)          # stable: the order inside a file is the file's own
 
 
+@pytest.fixture(autouse=True)
+def _lean_gpu_process(request):
+    """after every GPU test the pytest process hands its cached device memory back: the full-size cases (C3 / C5) leave
+    > 100 GB in PyTorch's caching allocator, and later tests start CHILD processes on the same GPU (two-rank DP, bench.py)"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
