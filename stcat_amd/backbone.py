@@ -157,6 +157,8 @@ class _BackboneFn(Function):
             if need_bwd and trainable:
                 tape.append((blk, x, o1, o2, y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
             x = y
+        if tape and tape[-1][4] is x:       # the last block's output is this node's output: keep a detached alias (no cycle
+            tape[-1] = tape[-1][:4] + (x.detach(),) + tape[-1][5:]      # through grad_fn: see _BackboneFnPl.forward)
         ctx.tape = tape
         ctx.body = body
         ctx.plist = weights
@@ -314,7 +316,11 @@ class _BackboneFnPl(Function):
             y, yf = conv(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last,
                          want_mask=tr_next)
             if need_bwd and blk.conv1.weight.requires_grad:
-                tape.append((blk, x, o1, o2, yf if last else y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
+                # (the LAST block's output is this node's own output: the tape keeps a detached alias of it — the output
+                #  object itself would close a reference cycle through its grad_fn that only backward() ever opened, and a
+                #  forward that is never back-propagated (a validation pass without no_grad) leaked its whole tape: 5 GB at
+                #  T = 16, found by the round-4 memory log of the GPU suite)
+                tape.append((blk, x, o1, o2, yf.detach() if last else y, (w1, w2, w3, wd), (s1, s2, s3, sd)))
             x = y
         for sd_ in sides:
             ops._wait_stream(main, sd_)

@@ -514,7 +514,10 @@ class BoxDecoderFn(Function):
         ctx.dims = (T, D, nl)
         ctx.refs = refs
         # ---- box head on the normalised states of all layers (pipeline.py:88-93): same bbox_embed as the anchor update
-        e1, x_h1 = _lin_f(hs.view(nl * T, D), Wb1, bb1, relu=True)
+        # (a DETACHED alias of hs: a view of the output itself, kept in ctx.head, would tie this node to its own output through
+        #  the view's base — a reference cycle that only backward() opens; a forward that is never back-propagated then keeps
+        #  the whole graph, the backbone's tape included, alive for the life of the process: round-4 memory log)
+        e1, x_h1 = _lin_f(hs.detach().view(nl * T, D), Wb1, bb1, relu=True)
         e2, x_h2 = _lin_f(e1, Wb2, bb2, relu=True)
         tmp, x_h3 = _lin_f(e2, Wb3, bb3)
         coord = ops.ew(L.EW_SIGMOID, ops.ew(L.EW_ADD, tmp, ops.ew(L.EW_INVSIG, refs.view(nl * T, 4))))

@@ -1135,30 +1135,40 @@ class LinearTransposes:
     criterion in drop-in mode, behaves as before)."""
 
     def __init__(self):
-        self.entries = {}      # (data_ptr, N, K) -> [weight view, transposed buffer, version, epoch]
+        self.entries = {}      # (data_ptr, N, K) -> [weakref to the weight's base tensor, transposed buffer, version, epoch]
         self.table = None
         self.total = 0
         self.dirty = True
 
+    @staticmethod
+    def _base(w: torch.Tensor) -> torch.Tensor:
+        return w._base if w._base is not None else w
+
     def get(self, w: torch.Tensor) -> torch.Tensor:
+        import weakref
         N, K = w.shape
         key = (w.data_ptr(), N, K)
         e = self.entries.get(key)
+        if e is not None and e[0]() is None:          # the weight died and its address was handed out again
+            e = None
         if e is not None and e[2] == w._version and e[3] == WEIGHT_EPOCH and e[1].device == w.device:
             return e[1]
         if e is None or e[1].device != w.device:
-            e = self.entries[key] = [w, torch.empty(K, N, device=w.device, dtype=_f32), -1, -1]
+            # (a WEAK reference: the cache must not keep the parameters of every model a process ever built alive)
+            e = self.entries[key] = [weakref.ref(self._base(w)), torch.empty(K, N, device=w.device, dtype=_f32), -1, -1]
             self.dirty = True
-            if len(self.entries) > 512:                     # (weights that keep moving: start over)
-                self.entries = {key: e}
-        e[0] = w
         L.call("stcat_weight_transpose", w.data_ptr(), e[1].data_ptr(), N, 1, K, L.stream_of(w))
         e[2], e[3] = w._version, WEIGHT_EPOCH
         return e[1]
 
     def refresh_all(self, like: torch.Tensor) -> None:
         import numpy as np
-        ents = [e for e in self.entries.values() if e[1].device == like.device]
+        dead = [k for k, e in self.entries.items() if e[0]() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.dirty = True
+        ents = [(k, e) for k, e in self.entries.items() if e[1].device == like.device]
         if not ents:
             return
         if self.dirty or self.table is None or self.table.device != like.device:
@@ -1169,16 +1179,17 @@ class LinearTransposes:
             assert dt.itemsize == L.load().stcat_weight_transpose_entry_bytes()
             tab = np.zeros(len(ents), dtype=dt)
             blk = 0
-            for i, (w, wt, _, _) in enumerate(ents):
-                N, K = w.shape
+            for i, ((ptr, N, K), e) in enumerate(ents):
                 nbx, nby = (K + 31) // 32, (N + 31) // 32
-                tab[i] = (w.data_ptr(), wt.data_ptr(), N, 1, K, blk, nbx, nby)
+                tab[i] = (ptr, e[1].data_ptr(), N, 1, K, blk, nbx, nby)
                 blk += nbx * nby
             self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(like.device)
             self.total, self.n, self.dirty = blk, len(ents), False
         L.call("stcat_weight_transpose_multi", self.table.data_ptr(), self.n, self.total, L.stream_of(like))
-        for e in ents:
-            e[2], e[3] = e[0]._version, WEIGHT_EPOCH
+        for _, e in ents:
+            base = e[0]()
+            if base is not None:
+                e[2], e[3] = base._version, WEIGHT_EPOCH
 
 
 LINEAR_WT = LinearTransposes()

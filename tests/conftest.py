@@ -66,6 +66,10 @@ def _lean_gpu_process(request):
             import torch
             if torch.cuda.is_available():
                 torch.cuda.empty_cache()
+                if os.environ.get("STCAT_TEST_MEMLOG"):      # leak hunting: live / reserved device memory after every test
+                    with open(os.environ["STCAT_TEST_MEMLOG"], "a") as f:
+                        f.write(f"{torch.cuda.memory_allocated() / 2**30:8.2f} GiB live {torch.cuda.memory_reserved() / 2**30:8.2f} "
+                                f"GiB reserved after {request.node.name}\n")
         except Exception:
             pass
 

@@ -24,6 +24,16 @@ def _release_parent_gpu_memory():
     yield
 
 
+def _child_errors(stderr: str) -> str:
+    """the ranks' own tracebacks (torchrun's summary at the end of stderr hides them)"""
+    lines = stderr.splitlines()
+    keep = [i for i, l in enumerate(lines) if "Error" in l or "error" in l or "Traceback" in l]
+    out = []
+    for i in keep[:12]:
+        out.extend(lines[max(0, i - 1):i + 4])
+    return "\n".join(out)[-6000:] or stderr[-3000:]
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_gloo_c3():
     """the benchmark configuration ITSELF (C3: T=64, 448 x 448) under two ranks — both share the box's one
@@ -36,7 +46,7 @@ def test_bench_two_ranks_gloo_c3():
            "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-exact", "--no-optim", "--no-profile"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _child_errors(r.stderr)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     # N > 1 exchanges the reference-sized message by default (327 MB of hot-path gradients + the 498 MB stand-in for the
