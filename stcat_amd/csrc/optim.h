@@ -79,7 +79,12 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* tab, co
   const long hi = lo + chunk < t.n ? lo + chunk : t.n;
   float coef = 1.f;
   if (h.max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
-    coef = h.max_norm / (sqrtf(*sqnorm) + 1e-6f);
+    const float sq = *sqnorm;
+    // A non-finite global gradient norm (an overflow: fp16 planes with too large a loss scale, a diverged step) SKIPS the
+    // whole update, as torch.cuda.amp.GradScaler.step does — clipping alone would turn inf * 0 into NaN weights.  The
+    // caller sees it in the squared norm AdamW.step() returns (optim.PlaneLossScale reads it).
+    if (!(sq <= 3.0e38f)) return;
+    coef = h.max_norm / (sqrtf(sq) + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
   }
   const float lr = h.lr[t.group], wd = h.wd[t.group];

@@ -303,3 +303,50 @@ def update_ema(model, model_ema, decay: float) -> None:
     tab.update(rows)
     L.call("stcat_ema_update", tab.table.data_ptr(), tab.chunk_tensor.data_ptr(), tab.chunk_off.data_ptr(),
            tab.n_chunks, CHUNK, float(decay), L.stream_of(any_t))
+
+
+
+class PlaneLossScale:
+    """Dynamic gradient (loss) scale of the experimental mma mode `f16x3p` — torch.cuda.amp.GradScaler's policy on the one
+    number that mode needs: every GRADIENT plane of the backbone holds dy * 2^log2 (fp16's range; csrc/igemm_pl.h), the
+    weight-gradient epilogue divides it out again, so the scale never reaches the optimizer.  An overflow shows up as a
+    non-finite global gradient norm: `AdamW.step(max_grad_norm=...)` then skips the update on the device, and `update()`
+    halves the scale; after `growth_interval` finite steps in a row it doubles (up to `max_log2`).  `update()` reads one
+    device scalar (a sync) every `check_every` steps.  Changing the scale invalidates the launch plans (they bake the
+    epilogue factor into their recorded arguments)."""
+
+    def __init__(self, init_log2: int = 16, growth_interval: int = 2000, check_every: int = 1, max_log2: int = 24):
+        self.log2 = int(init_log2)
+        self.growth_interval = int(growth_interval)
+        self.check_every = max(1, int(check_every))
+        self.max_log2 = int(max_log2)
+        self.good = 0
+        self.calls = 0
+        self.skipped = 0
+        self._apply()
+
+    def _apply(self):
+        from . import plans
+        wlog = L.load().stcat_get_f16_scale(0)
+        L.call("stcat_set_f16_scales", int(wlog), int(self.log2))
+        plans.invalidate()
+
+    def update(self, sqnorm) -> bool:
+        """sqnorm: what AdamW.step() returned.  -> True when the step was applied (finite norm)"""
+        self.calls += 1
+        if sqnorm is None or self.calls % self.check_every:
+            return True
+        ok = bool(torch.isfinite(sqnorm).all().item())
+        if not ok:
+            self.skipped += 1
+            self.good = 0
+            if self.log2 > 0:
+                self.log2 -= 1
+                self._apply()
+            return False
+        self.good += self.check_every
+        if self.good >= self.growth_interval and self.log2 < self.max_log2:
+            self.log2 += 1
+            self.good = 0
+            self._apply()
+        return True

@@ -4,6 +4,7 @@ learning-rate schedule of engine/lr_scheduler.py:212-252 against known values.""
 import copy
 from types import SimpleNamespace as NS
 
+import pytest
 import torch
 from torch import nn
 
@@ -165,3 +166,49 @@ def test_lr_schedule_values():
     cfg.SOLVER.SCHEDULE.TYPE = "multistep_with_warmup_all"
     optim.adjust_learning_rate(cfg, opt, 2, total)
     assert all(abs(g["lr"] - b * 0.2) < 1e-12 for g, b in zip(opt.param_groups, [3e-4, 2e-5, 5e-5, 1e-4]))
+
+
+@pytest.mark.gpu
+def test_gpu_fp16_plane_mode_overflow_skips_the_step_and_backs_the_scale_off():
+    """mode f16x3p with an absurd gradient scale (2^28: every gradient plane overflows fp16): the global gradient norm is
+    non-finite, AdamW.step() leaves the weights untouched (the clip alone would have made them NaN), and PlaneLossScale
+    halves the scale until a step goes through — then the weights move."""
+    import torch
+    from stcat_amd import _lib, optim, synth
+    from stcat_amd.misc import BoxList, NestedTensor
+    from stcat_amd.pipeline import SyntheticText, build_model
+    from tests.backends import use_hip
+    dev = use_hip()
+    T, res, L_ = 4, 128, 6
+    _lib.set_mma_mode("f16x3p")
+    try:
+        model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L_)))
+        model.eval()
+        synth.fill_module_(model)
+        model.to(dev)
+        opt = optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+        scaler = optim.PlaneLossScale(init_log2=28, growth_interval=1000)
+        frames = synth.synth_frames(T, res).to(dev)
+        mask = torch.zeros(T, res, res, dtype=torch.bool, device=dev)
+        act, tb = synth.synth_targets(T)
+        tgt = [{"actioness": act.to(dev), "boxs": BoxList(tb, (res, res)).to(dev)}]
+        probe = model.vis_encoder[0].body.layer3[0].conv2.weight
+        w0 = probe.detach().clone()
+        applied = []
+        for k in range(24):
+            opt.zero_grad()
+            out = model(NestedTensor(frames, mask, [T]), ["q"])
+            l = criterion(out, tgt, [T])
+            sum(l[n] * wd[n] for n in l).backward()
+            ok = scaler.update(opt.step(max_grad_norm=0.1))
+            applied.append(ok)
+            if not ok:
+                assert torch.equal(probe.detach(), w0), "a skipped step must not touch the weights"
+            else:
+                break
+        assert applied[0] is False and applied[-1] is True, applied          # overflowed first, recovered by backing off
+        assert scaler.skipped >= 1 and scaler.log2 < 28
+        assert torch.isfinite(probe).all() and not torch.equal(probe.detach(), w0)
+    finally:
+        _lib.call("stcat_set_f16_scales", 6, 16)
+        _lib.set_mma_mode("f32")
