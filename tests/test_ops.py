@@ -116,8 +116,6 @@ def _conv_case(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile=None):
         dw = ops.conv_wgrad_raw(G, xd, wd.shape, stride, pad)
         dx2 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, add=dx.clone())
         ymask = torch.randn_like(xd)
-        if f16:      # fp16 planes flush |y| < 6e-8 to zero: the plane-derived ReLU mask (a path the model does not use: it
-            ymask = torch.where(ymask.abs() < 1e-4, torch.full_like(ymask, 1e-4), ymask)   # reads bit masks) needs y off zero
         msc = torch.rand(xd.shape[-1], device=dev) + 0.5
         dx3 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, mask_y=ymask, mask_scale=msc)
         dx4, dx5 = ops.conv_dgrad_raw(G, wd, xd.shape, stride, pad, add=dx.clone(), mask_y=ymask, scale2=msc)
