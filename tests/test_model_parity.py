@@ -500,10 +500,12 @@ def test_emu_train_mode_against_oracle():
 
 
 @pytest.mark.gpu
-def test_gpu_train_mode_against_oracle():
-    """C1 (T=8, 224 x 224, L=10) in the default arithmetic, dropout on, against the oracle fed with the kernels' masks"""
+@pytest.mark.parametrize("mma", [BENCH_MMA, "f16x3p"])
+def test_gpu_train_mode_against_oracle(mma):
+    """C1 (T=8, 224 x 224, L=10), dropout on, against the oracle fed with the kernels' masks — in the default arithmetic
+    and in the experimental fp16-plane mode"""
     T, res, L = synth.CONFIGS["C1"]
-    _check_train_mode_against_oracle(use_hip(), T, res, L, mma=BENCH_MMA)
+    _check_train_mode_against_oracle(use_hip(), T, res, L, mma=mma)
 
 
 def test_emu_train_mode_dropout():
@@ -723,6 +725,13 @@ def _run_bench_step(dev, name, mma, steps=3, train=False):
         if ts is not None:
             ts.close()
         _lib.set_mma_mode("f32")
+
+
+@pytest.mark.gpu
+def test_gpu_c3_replayed_bench_step_fp16_planes():
+    """the same replayed C3 step in the experimental mode f16x3p (what `near_f32_mode` of the bench line times)"""
+    dev = use_hip()
+    _compare(_run_bench_step(dev, "C3", "f16x3p"), Ref.fixture("C3"))
 
 
 @pytest.mark.gpu
