@@ -176,6 +176,18 @@ int stcat_linear_fwd_acc(const float* x, const float* w, const float* bias, cons
                          int K, int ldx, int ldy, int ldr, void* stream);
 int stcat_linear_dgrad_acc(const float* g, const float* w, const float* add, float* dx, int M, int N, int K, int ldg,
                            int lddx, void* stream);
+/* The feed-forward block's `dropout(activation(linear1(x)))` (modal_encoder.py:239-240, query_decoder.py:435-436,
+ * 657-658) as ONE launch: y = dropout_p(relu?(x w^T + bias (+ res))), the dropout decision of element (m, n) drawn from
+ * counter drop_offset + m * N + n of the site (what stcat_dropout draws on the dense [M,N] tensor).  Dense output
+ * (ldy == N); split-bf16 modes only. */
+int stcat_linear_fwd_drop(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                          int K, int ldx, int ldy, int ldr, int relu, float drop_p, long drop_seed, long drop_offset,
+                          const long* drop_base, void* stream);
+/* ... and the backward of that pair folded into the data gradient of linear2 (modal_encoder.py:240, the autograd
+ * of `linear2(dropout(relu(.)))`): dx = [mask_y > 0] * mask_gain * (g . w (+ add)), where mask_y = the forward's
+ * dropout(relu(.)) output (positive <=> ReLU passed and the element was kept) and mask_gain = 1 / (1 - p). */
+int stcat_linear_dgrad_mask(const float* g, const float* w, const float* add, const float* wt, const float* mask_y,
+                            float mask_gain, float* dx, int M, int N, int K, int ldg, int lddx, void* stream);
 /* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0.  db (may be NULL; caller-zeroed,
  * needs ldg == N) += column sums of g — the bias gradient of the same nn.Linear, summed inside the launch */
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,

@@ -62,10 +62,11 @@ def _lin_f(x, w, b, res=None, relu=False):
     return y.view(*shp[:-1], w.shape[0]), x2
 
 
-def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want_db=True):
+def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want_db=True, mask=None):
     """backward of y = relu?(x2 w^T + b (+ res)): returns (dx [M,K] | None, dw, db, g_after_relu).  `dw` / `db`: zeroed
     buffers to accumulate into (row blocks of a packed parameter's gradient); `add`: [M,K] tensor summed into dx inside
-    the data-gradient launch."""
+    the data-gradient launch.  `mask` = (y [M,K], gain): the Linear's INPUT was y = dropout(relu(.)) — its ReLU and
+    dropout backward ride in the data gradient's epilogue (dx = [y > 0] * gain * (g w))."""
     N, K = w.shape
     g = g.reshape(-1, N)
     g = g if g.is_contiguous() else g.contiguous()
@@ -79,8 +80,15 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
             if add is not None:
                 add = add.reshape(M, K)
                 add = add if add.is_contiguous() else add.contiguous()
-            dx = ops._zero_take(g, (M, K)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32") else None
-            if dx is not None:       # skinny: zeroed output, reduction split over grid.z (see ops.linear_fwd_raw)
+            dx = (ops._zero_take(g, (M, K)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32" and mask is None)
+                  else None)
+            if mask is not None:
+                my, gain = mask
+                dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+                wt = ops.LINEAR_WT.get(w) if M > 256 else None
+                L.call("stcat_linear_dgrad_mask", g.data_ptr(), w.data_ptr(), L._ptr(add), L._ptr(wt), my.data_ptr(),
+                       float(gain), dx.data_ptr(), M, N, K, N, K, st)
+            elif dx is not None:       # skinny: zeroed output, reduction split over grid.z (see ops.linear_fwd_raw)
                 L.call("stcat_linear_dgrad_acc", g.data_ptr(), w.data_ptr(), L._ptr(add), dx.data_ptr(), M, N, K, N, K, st)
             else:
                 dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
@@ -119,9 +127,13 @@ _DIRTY = [False]     # the side stream holds launches the current stream has not
 DEFER_WGRADS = not os.environ.get("STCAT_NO_WGRAD_DEFER")
 
 
+INLINE_TIME_WGRADS = not os.environ.get("STCAT_TIME_WGRADS_DEFERRED")
+PROJ_LANE = not os.environ.get("STCAT_NO_PROJ_LANE")
+
+
 def _wgrad(g, x2, dw, db, M, N, K):
     args = (g.data_ptr(), x2.data_ptr(), dw.data_ptr(), L._ptr(db), M, N, K, N, x2.stride(0))
-    if _BATCH and DEFER_WGRADS:
+    if _BATCH and _BATCH[-1] is not None and DEFER_WGRADS:
         _BATCH[-1].append((args, g, x2))
     else:
         L.call("stcat_linear_wgrad", *args, L.stream_of(g))
@@ -129,7 +141,7 @@ def _wgrad(g, x2, dw, db, M, N, K):
 
 def wgrad_flush(like: torch.Tensor) -> None:
     """issue what the innermost batch has collected so far (end of a decoder layer inside its node's batch)"""
-    if not _BATCH or not _BATCH[-1]:
+    if not _BATCH or not _BATCH[-1]:       # (no batch, an empty one, or a None frame: launches went out directly)
         return
     pending = _BATCH[-1]
     _BATCH[-1] = []
@@ -165,6 +177,48 @@ class wgrad_batch:
         return False
 
 
+class _Lane:
+    """a second launch lane beside a node's dependent chain (one of the package's measured-concurrent side streams):
+    `fork()` orders it behind everything queued on the current stream, `with lane:` queues launches on it, `sync_main()`
+    makes the current stream wait for what the lane holds SO FAR (launches queued on the lane afterwards run beside the
+    chain), `keep(...)` tells the allocator / the recording plan that the lane touches these tensors."""
+
+    def __init__(self, like: torch.Tensor, index: int, enabled: bool = True):
+        self.active = bool(enabled and ops.FORK_ENABLED and L._backend == "hip" and like.is_cuda)
+        if self.active:
+            self.main = torch.cuda.current_stream(like.device)
+            self.side = ops.side_stream(like.device, index)
+            self.active = self.side.cuda_stream != self.main.cuda_stream
+        self.ctx = None
+
+    def fork(self):
+        if self.active:
+            ops._wait_stream(self.side, self.main)
+
+    def sync_main(self):
+        if self.active:
+            ops._wait_stream(self.main, self.side)
+
+    def __enter__(self):
+        if self.active:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def keep(self, *tensors):
+        if self.active:
+            for t in tensors:
+                if torch.is_tensor(t):
+                    t.record_stream(self.side)
+                    if L.RECORDER is not None:
+                        L.RECORDER.keep.append(t)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # shared sub-blocks
 # ------------------------------------------------------------------------------------------------------------------
@@ -179,19 +233,42 @@ def _outln_f(a, Wo, bo, res, g, be, p):
     return y, (c_n, x_o, Wo, p, y.shape)
 
 
-def _outln_b(st, dy, need_da=True):
-    """-> (d_a [M,K], d_res (shape of y), dWo, dbo, dg, dbe)"""
+def _outln_b(st, dy, need_da=True, mask=None):
+    """-> (d_a [M,K], d_res (shape of y), dWo, dbo, dg, dbe); mask: see _lin_b (the FFN's fused ReLU + dropout backward)"""
     c_n, x_o, Wo, p, shp = st
     r = ops.LayerNormFn.backward(c_n, dy.reshape(shp))
     d_h, d_res, dg, dbe = r[0], r[1], r[2], r[3]
     if p == 0.0:
         d_res = d_h
-    d_a, dWo, dbo, _ = _lin_b(d_h, x_o, Wo, need_dx=need_da)
+    d_a, dWo, dbo, _ = _lin_b(d_h, x_o, Wo, need_dx=need_da, mask=mask)
     return d_a, d_res, dWo, dbo, dg, dbe
 
 
+FUSE_FFN = not os.environ.get("STCAT_NO_FFN_FUSE")
+
+
 def _ffn_f(x, W1, b1, W2, b2, g, be, p):
-    """norm(x + dropout(linear2(dropout(relu(linear1 x)))))  (modal_encoder.py:239-241; query_decoder.py:435-437, 657-659)"""
+    """norm(x + dropout(linear2(dropout(relu(linear1 x)))))  (modal_encoder.py:239-241; query_decoder.py:435-437, 657-659).
+    Round 5: the ReLU AND the inner dropout ride in linear1's epilogue (stcat_linear_fwd_drop), their backward in the
+    epilogue of linear2's data gradient (stcat_linear_dgrad_mask): per layer one [M, 2048] pass less forward (the dropout
+    launch) and two less backward (dropout + ReLU backward) — 125 us per spatial encoder layer at C3 — and the pre-dropout
+    activation is no longer kept.  The split-bf16 modes only; mma mode f32 keeps the separate launches."""
+    if FUSE_FFN and L.get_mma_mode() != "f32" and W1.shape[0] % 64 == 0:
+        shp = x.shape
+        K = shp[-1]
+        x2 = x if x.dim() == 2 else x.reshape(-1, K)
+        if not (x2.is_contiguous() or (x2.stride(1) == 1 and x2.stride(0) % 4 == 0)):
+            x2 = x2.contiguous()
+        M, N = x2.shape[0], W1.shape[0]
+        if p > 0.0:
+            seed, off, base = ops._dropout_stream.take(M * N, x.device)
+            f1d = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            L.call("stcat_linear_fwd_drop", x2.data_ptr(), W1.data_ptr(), L._ptr(b1), None, f1d.data_ptr(), M, N, K,
+                   x2.stride(0), N, 0, 1, float(p), seed, off, base, L.stream_of(x2))
+        else:
+            f1d = ops.linear_fwd_raw(x2, W1, b1, None, True)
+        y, st = _outln_f(f1d.view(*shp[:-1], N), W2, b2, x, g, be, p)
+        return y, (st, ("fused", 1.0 / (1.0 - p) if p > 0.0 else 1.0), x2, f1d, W1)
     f1, x_1 = _lin_f(x, W1, b1, relu=True)
     c_dr = None
     f1d = f1
@@ -204,6 +281,10 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p):
 def _ffn_b(st, dy):
     """-> (d_x [M,D], dW1, db1, dW2, db2, dg, dbe)"""
     st_o, c_dr, x_1, f1, W1 = st
+    if isinstance(c_dr, tuple) and c_dr[0] == "fused":
+        d_f1, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy, mask=(f1, c_dr[1]))     # f1 = dropout(relu(.)) here
+        d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, add=d_x_res)
+        return d_x, dW1, db1, dW2, db2, dg, dbe
     d_f1d, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy)
     d_f1 = ops.DropoutFn.backward(c_dr, d_f1d.view(f1.shape))[0] if c_dr is not None else d_f1d
     d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, relu_y=f1, add=d_x_res)      # + residual gradient, fused into the dgrad
@@ -350,6 +431,17 @@ class TimeDecoderFn(Function):
 
     @staticmethod
     def backward(ctx, d_hs, d_ws):
+        # Round 5: this node's weight gradients stay ON its own chain (no hand-over to the shared weight-gradient stream).
+        # The node runs on the forked stream beside the box decoder, whose ~330 weight-gradient launches fill that stream
+        # first (the host replays the box decoder's backward before this one): this node's ~100 launches queued behind them
+        # and its final join — which the encoder's backward waits for — came 0.9 ms after the box decoder had finished
+        # (tools/node_times.py: 3.75 ms against 2.86 ms).  Inline they lengthen this chain to ~2.8 ms, still the shorter one.
+        if INLINE_TIME_WGRADS:
+            _BATCH.append(None)          # (a None frame: _wgrad launches directly, nested flushes are no-ops)
+            try:
+                return TimeDecoderFn._backward(ctx, d_hs, d_ws)
+            finally:
+                _BATCH.pop()
         with wgrad_batch(d_hs):
             return TimeDecoderFn._backward(ctx, d_hs, d_ws)
 
@@ -448,6 +540,27 @@ class BoxDecoderFn(Function):
         ops.ew(L.EW_COPY, anchor, out=refs[0])
         out = ops._zeros(anchor, T, D)
         states = []
+        # Round 5: the memory-side projections of a layer (ca_kpos_proj(pos), ca_v_proj(memory), ca_kcontent_proj(memory),
+        # query_decoder.py:355-358 — three [n*S', 256] x 256 GEMMs, 72 us of a layer's 370 us chain at C3) do not depend on
+        # the query state: layer i + 1's run on a second lane (the weight-gradient stream, idle in the forward pass) while
+        # the chain works through layer i; the chain waits for them right before its cross-attention.
+        lane = _Lane(memory, 1, PROJ_LANE)
+        x_pos, x_mem = pos.reshape(-1, D), memory.reshape(-1, D)
+        rows = x_mem.shape[0]
+
+        def mem_proj(i):
+            lpm = prm[_N_SHARED + i * _N_LAYER + 36: _N_SHARED + (i + 1) * _N_LAYER]
+            (Wmk_, bmk_, Wmp_, bmp_, Wmv_, bmv_) = lpm
+            kpi_, vvi_, kci_ = (ops._empty(memory, rows, D) for _ in range(3))     # (allocated on the chain's stream)
+            with lane:
+                ops.linear_fwd_raw(x_pos, Wmp_, bmp_, out=kpi_)                                # :355-358
+                ops.linear_fwd_raw(x_mem, Wmv_, bmv_, out=vvi_)
+                ops.linear_fwd_raw(x_mem, Wmk_, bmk_, kpi_ if i == 0 else None, out=kci_)      # first layer: + k_pos :360-366
+            lane.keep(kpi_, vvi_, kci_)
+            return (kci_.view(memory.shape), kpi_.view(memory.shape), vvi_.view(memory.shape))
+
+        lane.fork()
+        nxt = mem_proj(0)
         for i in range(nl):
             lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]
             (Wqc, bqc, Wqp, bqp, Wqt, bqt, Wkc, bkc, Wkp, bkp, Wkt, bkt, Wv, bv, W_in, B_in, Wo, bo, g1, be1, Wcq, bcq,
@@ -483,14 +596,13 @@ class BoxDecoderFn(Function):
             st["sa_in"] = (out, qpos, q, k, v)
             # ---- time-aligned cross-attention :355-432
             qc, _ = _lin_f(tgt1, Wcq, bcq)
-            kpi, x_pos = _lin_f(pos, Wmp, bmp)                                                # :355-358
-            vvi, x_mem = _lin_f(memory, Wmv, bmv)
             if first:                                                                        # :360-366
                 qc, _ = _lin_f(qpos, Wcqp, bcqp, res=qc)
-                kci, _ = _lin_f(memory, Wmk, bmk, res=kpi)
-            else:
-                kci, _ = _lin_f(memory, Wmk, bmk)
             qs, st["x_qs"] = _lin_f(sine_q, Wqs, bqs)                                        # :369
+            kci, kpi, vvi = nxt
+            lane.sync_main()                       # this layer's memory-side projections (queued a layer ago) are in
+            if i + 1 < nl:
+                nxt = mem_proj(i + 1)              # ... the next layer's start now, beside the rest of this layer
             a2, st["q1"] = _f(ops.AttnQ1Fn, _T, qc, qs, kci, kpi, vvi, kpm, (2 * hd) ** -0.5, p)
             tgt2, st["o3"] = _outln_f(a2, Wo2, bo2, tgt1, g3, be3, p)
             st["tgt1"] = tgt1

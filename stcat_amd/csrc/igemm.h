@@ -18,6 +18,7 @@
 // N-tiles sharing one activation row-block run back-to-back on the same XCD (L2 reuse).
 #pragma once
 #include "stcat_platform.h"
+#include "stcat_rng.h"
 
 struct IgemmGeom {
   int H, W, C, ld;         // gathered NHWC tensor: spatial dims, channels, pixel stride (floats)
@@ -59,6 +60,12 @@ struct IgemmParams {
   int k_chunk;  // wgrad: rows of the M reduction per grid.z slice (multiple of 16)
   unsigned a_bytes, b_bytes;  // extents of A and B for the bounds-checked buffer loads (split-bf16 kernels)
   unsigned b_tap_stride;      // split-bf16 fwd-path B addressing: byte offset of K-tile = tap*b_tap_stride + c0*4
+  // split-bf16 forward kernel only (round 5): dropout applied to the epilogue's result (after bias / residual / ReLU),
+  // element index m * N + n of the site's counter range — the FFN's `dropout(relu(linear1 x))` (modal_encoder.py:239,
+  // query_decoder.py:435, 657) without its own pass over the [M, 2048] tensor
+  DropParams drop;
+  float mask_gain;            // with `mask`: the kept elements are also multiplied by this (0 = 1): the 1 / (1 - p) of a dropout
+                              // whose output IS the mask tensor (y > 0 <=> ReLU passed and the element was kept)
   IgemmGeom g;
 };
 

@@ -264,10 +264,17 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
       v4.x += rr.x; v4.y += rr.y; v4.z += rr.z; v4.w += rr.w;                                            \
     }                                                                                                    \
     if (p.relu) { v4.x = fmaxf(v4.x, 0.f); v4.y = fmaxf(v4.y, 0.f); v4.z = fmaxf(v4.z, 0.f); v4.w = fmaxf(v4.w, 0.f); } \
+    if (p.drop.thresh) {                                                                                 \
+      const DropParams dp_ = stcat_drop_resolve(p.drop);                                                 \
+      const unsigned long long i0_ = (unsigned long long)(m) * (unsigned long long)p.N + (unsigned long long)(n); \
+      v4.x *= stcat_drop_mul(dp_, i0_); v4.y *= stcat_drop_mul(dp_, i0_ + 1);                            \
+      v4.z *= stcat_drop_mul(dp_, i0_ + 2); v4.w *= stcat_drop_mul(dp_, i0_ + 3);                        \
+    }                                                                                                    \
     if (p.mask) {                                                                                        \
       const float4 mk = stcat_ld4(p.mask + (long)(m) * p.ldc + (n));                                     \
-      float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);                                                       \
-      if (p.mscale) ms = stcat_ld4(p.mscale + (n));                                                      \
+      const float mg_ = p.mask_gain != 0.f ? p.mask_gain : 1.f;                                          \
+      float4 ms = make_float4(mg_, mg_, mg_, mg_);                                                       \
+      if (p.mscale) { ms = stcat_ld4(p.mscale + (n)); ms.x *= mg_; ms.y *= mg_; ms.z *= mg_; ms.w *= mg_; } \
       v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;                      \
       v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;                      \
     }                                                                                                    \
@@ -502,8 +509,9 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
       }
       if (p.mask) {  // fused ReLU+BN backward of the layer below
         const float4 mk = stcat_ld4(p.mask + (long)m * p.ldc + n);
-        float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.mscale) ms = stcat_ld4(p.mscale + n);
+        const float mg_ = p.mask_gain != 0.f ? p.mask_gain : 1.f;
+        float4 ms = make_float4(mg_, mg_, mg_, mg_);
+        if (p.mscale) { ms = stcat_ld4(p.mscale + n); ms.x *= mg_; ms.y *= mg_; ms.z *= mg_; ms.w *= mg_; }
         v4.x = mk.x > 0.f ? v4.x * ms.x : 0.f; v4.y = mk.y > 0.f ? v4.y * ms.y : 0.f;
         v4.z = mk.z > 0.f ? v4.z * ms.z : 0.f; v4.w = mk.w > 0.f ? v4.w * ms.w : 0.f;
       }

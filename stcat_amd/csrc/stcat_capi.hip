@@ -825,6 +825,63 @@ int stcat_linear_dgrad_acc(const float* g, const float* w, const float* add, flo
   return rc;
 }
 
+// y = dropout_p(relu?(x w^T + bias (+ res))): the FFN's first Linear with its ReLU and dropout in ONE epilogue
+// (modal_encoder.py:239-240, query_decoder.py:435-436, 657-658: `dropout(activation(linear1(x)))`).  Element (m, n) of
+// the site draws counter drop_offset + m * N + n, exactly what stcat_dropout draws on the dense [M, N] tensor.
+int stcat_linear_fwd_drop(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N,
+                          int K, int ldx, int ldy, int ldr, int relu, float drop_p, long drop_seed, long drop_offset,
+                          const long* drop_base, void* stream) {
+  if (N % 64 != 0 || K % 32 != 0) return fail("linear_fwd_drop: need N %% 64 == 0, K %% 32 == 0 (N=%d K=%d)", N, K);
+  if (ldx % 4 != 0 || !aligned16(x) || !aligned16(w)) return fail("linear_fwd_drop: x/w must be 16-byte aligned rows");
+  if (M <= 0 || ldy != N) return fail("linear_fwd_drop: dense output rows expected (M=%d ldy=%d N=%d)", M, ldy, N);
+  if (g_mma_mode == 0) return fail("linear_fwd_drop: the fused form runs on the split-bf16 kernels (not in mma mode f32)");
+  IgemmParams p = {};
+  p.A = x; p.B = w; p.C = y; p.bias = bias; p.res = res;
+  p.a_bytes = bytes_of((long)(M - 1) * ldx + K); p.b_bytes = bytes_of((long)N * K);
+  p.b_tap_stride = (unsigned)K * 4;
+  p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = ldy; p.ldr = ldr;
+  p.c_group = M; p.relu = relu;
+  p.scale = nullptr;
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
+  p.g = conv_geom_fwd(1, 1, K, ldx, 1, 1, 1, 1, 1, 0);
+  if (!bs_ok(p)) return fail("linear_fwd_drop: operands too large for the bounds-checked loads");
+  // (launched directly: the split-K form of launch_fwd has no place for a non-linear epilogue)
+  int BM, BN;
+  pick_tile(p.M, p.N, BM, BN);
+  if (BM == 256) BM = 128;
+  const dim3 grid(cdiv(p.M, BM) * (p.N / BN));
+  hipStream_t st = (hipStream_t)stream;
+  if (g_mma_mode == 3) { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 3) } else { STCAT_TILE_SWITCH_BS(igemm_bs_fwd_kernel, grid, 2) }
+  return launch_status();
+}
+
+// dx = [mask_y > 0] * mask_gain * (g w (+ add)): the data gradient of a Linear whose INPUT was `mask_y = dropout(relu(.))`
+// — ReLU backward and dropout backward in the epilogue (mask_y > 0 <=> the ReLU passed AND the element was kept;
+// mask_gain = 1 / (1 - p)).  wt = w^T [K, N] (optional: the transposed-operand kernel, as in stcat_linear_dgrad).
+int stcat_linear_dgrad_mask(const float* g, const float* w, const float* add, const float* wt, const float* mask_y,
+                            float mask_gain, float* dx, int M, int N, int K, int ldg, int lddx, void* stream) {
+  if (K % 64 != 0 || N % 32 != 0) return fail("linear_dgrad_mask: need K %% 64 == 0, N %% 32 == 0 (N=%d K=%d)", N, K);
+  if (ldg % 4 != 0 || !aligned16(g) || !aligned16(w)) return fail("linear_dgrad_mask: g/w must be 16-byte aligned rows");
+  if (!mask_y || lddx != K) return fail("linear_dgrad_mask: mask_y and a dense dx are required");
+  if (g_mma_mode == 0) return fail("linear_dgrad_mask: the fused form runs on the split-bf16 kernels (not in mma mode f32)");
+  IgemmParams p = {};
+  p.A = g; p.B = w; p.C = dx; p.res = add; p.mask = mask_y; p.mask_gain = mask_gain;
+  p.a_bytes = bytes_of((long)(M - 1) * ldg + N); p.b_bytes = bytes_of((long)N * K);
+  p.M = M; p.N = K; p.K = N; p.ldb = K; p.ldc = lddx; p.ldr = lddx;
+  p.c_group = M; p.relu = 0;
+  IgemmGeom q;
+  q.H = 1; q.W = 1; q.C = N; q.ld = ldg; q.OH = 1; q.OW = 1; q.KH = 1; q.KW = 1;
+  q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
+  p.g = q;
+  if (!bs_ok(p)) return fail("linear_dgrad_mask: operands too large for the bounds-checked loads");
+  if (wt) {  // wt = w^T [K][N]: the forward kernel's staging path
+    IgemmParams t = p;
+    t.B = wt; t.ldb = N; t.b_tap_stride = 0;
+    return launch_fwd(t, (hipStream_t)stream);
+  }
+  return launch_dgrad(p, (hipStream_t)stream);
+}
+
 int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);
 
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,
@@ -1387,6 +1444,8 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_linear_dgrad),
     STCAT_PLAN_FN(stcat_linear_fwd_acc),
     STCAT_PLAN_FN(stcat_linear_dgrad_acc),
+    STCAT_PLAN_FN(stcat_linear_fwd_drop),
+    STCAT_PLAN_FN(stcat_linear_dgrad_mask),
     STCAT_PLAN_FN(stcat_linear_wgrad),
     STCAT_PLAN_FN(stcat_small_linear_fwd),
     STCAT_PLAN_FN(stcat_small_linear_bwd),

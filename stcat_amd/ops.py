@@ -1152,7 +1152,16 @@ class LinearTransposes:
         if e is not None and e[0]() is None:          # the weight died and its address was handed out again
             e = None
         if e is not None and e[2] == w._version and e[3] == WEIGHT_EPOCH and e[1].device == w.device:
-            return e[1]
+            # a cache hit while a launch plan is being RECORDED leaves the transpose launch out of the plan; a
+            # replay is then only right if somebody refreshed this W^T earlier in the step (StgLossFn.backward does, a
+            # foreign criterion or a second pass without an update does not).  The plan therefore carries a host-side
+            # prerequisite: before every replay the entry is checked against the weight's version / WEIGHT_EPOCH and
+            # re-transposed on the spot when it is stale.  (Under hipGraph capture there is no such hook: emit the launch.)
+            if L.RECORDER is not None:
+                L.RECORDER.prereq(lambda key=key: self._ensure(key))
+                return e[1]
+            if not (w.is_cuda and torch.cuda.is_current_stream_capturing()):
+                return e[1]
         if e is None or e[1].device != w.device:
             # (a WEAK reference: the cache must not keep the parameters of every model a process ever built alive)
             e = self.entries[key] = [weakref.ref(self._base(w)), torch.empty(K, N, device=w.device, dtype=_f32), -1, -1]
@@ -1160,6 +1169,17 @@ class LinearTransposes:
         L.call("stcat_weight_transpose", w.data_ptr(), e[1].data_ptr(), N, 1, K, L.stream_of(w))
         e[2], e[3] = w._version, WEIGHT_EPOCH
         return e[1]
+
+    def _ensure(self, key) -> None:
+        """replay-time check of one entry (see get): transpose now if the weight moved on since the entry was written"""
+        e = self.entries.get(key)
+        base = e[0]() if e is not None else None
+        if base is None:
+            return
+        if e[2] != base._version or e[3] != WEIGHT_EPOCH:
+            ptr, N, K = key
+            L.call("stcat_weight_transpose", ptr, e[1].data_ptr(), N, 1, K, L.stream_of(base))
+            e[2], e[3] = base._version, WEIGHT_EPOCH
 
     def refresh_all(self, like: torch.Tensor) -> None:
         import numpy as np

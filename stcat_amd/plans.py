@@ -142,6 +142,7 @@ class Recorder:
         self.calls = []                         # (first word, signature, words)
         self.memsets = []
         self.effects = []
+        self.prereqs = []
         self.yields = []
         self.keep: List[torch.Tensor] = []
         self.foreign: List[str] = []
@@ -216,6 +217,11 @@ class Recorder:
         """a host-side state change of the region (dropout bookkeeping): repeated after every replay"""
         self.effects.append(fn)
 
+    def prereq(self, fn) -> None:
+        """a host-side check the region relied on WITHOUT launching anything (a cached W^T that was current at record
+        time, ops.LinearTransposes.get): run before every replay, on the replay's stream; it may launch eagerly"""
+        self.prereqs.append(fn)
+
     def zeros(self, shape) -> torch.Tensor:
         """a zeroed fp32 buffer from the plan's accumulation chunks.  A chunk is cleared by ONE memset op that sits at the
         point of the sequence where the chunk was opened, on the stream that opened it (its block may have served an
@@ -287,6 +293,7 @@ class Plan:
         self.side_handles = list(rec.side_handles)
         self.side_streams = list(rec.side_streams)
         self.effects = list(rec.effects)
+        self.prereqs = list(rec.prereqs)
         self.yields = list(rec.yields)
         self.keep = rec.keep
         self.n_ext = len(rec.ext)
@@ -304,6 +311,8 @@ class Plan:
     def run(self, ext: List[Optional[torch.Tensor]]) -> None:
         lib = self.lib
         t0 = time.perf_counter()
+        for f in self.prereqs:
+            f()
         extv = self._ext_t(*[0 if t is None else t.data_ptr() for t in ext])
         if self.cuda:
             self._streams[0] = torch._C._cuda_getCurrentRawStream(self.dev.index if self.dev.index is not None

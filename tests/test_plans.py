@@ -230,6 +230,65 @@ def test_emu_recording_refuses_a_node_that_runs_foreign_kernels():
         plans.clear()
 
 
+class _LinearNode(torch.autograd.Function):
+    """y = x w^T + b with the composite layers' own backward (`composite._lin_b`): rows > 256 take the data gradient
+    through the CACHED transposed weight (ops.LinearTransposes.get)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return ops.linear_fwd_raw(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        from stcat_amd import composite
+        x, w = ctx.saved_tensors
+        dx, dw, db, _ = composite._lin_b(g, x, w)
+        return dx, dw, db
+
+
+def _cached_transpose_case(dev):
+    """a plan recorded while LinearTransposes.get() HIT its cache holds no transpose launch; with a
+    loss that is not StgLossFn nobody refreshes W^T before the replay.  The weights move between the steps (an optimizer
+    update): every step's dx must be g . W of THAT step's W."""
+    _lib.set_mma_mode("f32" if dev.type == "cpu" else "bf16x6")
+    plans.clear()
+    plans.enable(True)
+    plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0)
+    try:
+        gen = torch.Generator().manual_seed(3)
+        M, K, N = 320, 64, 64
+        w = torch.nn.Parameter(torch.randn(N, K, generator=gen).to(dev))
+        b = torch.nn.Parameter(torch.zeros(N, device=dev))
+        for k in range(5):
+            x0 = torch.randn(M, K, generator=gen).to(dev).requires_grad_(True)
+            x = x0 * 1.0
+            w.grad = b.grad = None
+            y = plans.apply(_LinearNode, x, w, b)
+            gy = torch.randn(M, N, generator=gen).to(dev)
+            y.backward(gy)
+            want = gy.double().cpu() @ w.detach().double().cpu()
+            err = (x0.grad.double().cpu() - want).abs().max().item() / want.abs().max().item()
+            assert err < 2e-5, (k, err, plans.STATS)
+            if k >= 1:        # (no update between the eager call and the recording: the recording HITS the cache)
+                with torch.no_grad():
+                    w.add_(0.5 * torch.randn(N, K, generator=gen).to(dev))     # the "optimizer step": version bump, same storage
+        assert plans.STATS["replayed"] >= 4, plans.STATS      # forward + backward of steps 3.. came out of the plans
+    finally:
+        plans.enable(False)
+        plans.clear()
+
+
+def test_emu_replay_checks_the_cached_weight_transposes():
+    _cached_transpose_case(use_emu())
+
+
+@pytest.mark.gpu
+def test_gpu_replay_checks_the_cached_weight_transposes():
+    from tests.backends import use_hip
+    _cached_transpose_case(use_hip())
+
+
 @pytest.mark.gpu
 def test_gpu_plans_follow_load_state_dict_and_mode_switch():
     """(medium) replays skip FrozenBatchNorm2d.folded() and the weight-table key checks, so whatever rewrites
