@@ -11,6 +11,7 @@
 #include "igemm.h"
 #include "igemm_bs.h"
 #include "igemm_pl.h"
+#include "igemm_pl_as.h"
 #include "pointwise.h"
 #include "loss.h"
 
@@ -347,6 +348,7 @@ int pl_prepare(K kernel, int lds_bytes) {
   }
 
 int g_pl_debug = 0;   // stcat_debug_pl_flags (timing experiments)
+int g_pl_as = 1;      // stcat_debug_pl_flags bit 7 (128) switches the A-stationary kernel off (A/B against the two-stage kernel)
 int g_pl_force = -1;  // stcat_debug_force_pl_tile: index into the tile table below, -1 = heuristic
 struct PlTile { int bm, bn; float eff; };
 // relative cost per MAC of each tile shape (bigger wave tiles amortise fragment reads and DMA issue better)
@@ -362,7 +364,7 @@ const PlTile kPlTiles[7] = {{256, 256, 1.00f}, {256, 128, 1.12f}, {128, 256, 1.1
 const float kPl3Eff[7] = {0.f, 1.00f, 0.97f, 1.15f, 1.20f, 0.f, 1.60f};   // indexed like kPlTiles; 0 = not available
 int g_pl3_small = 0;   // stcat_debug_pl_flags bit 2 sets it: the two-workgroup 128 x 64 tile for short reductions
 int pick_pl3_tile(int M, int N, int K) {
-  if (g_pl_force >= 0) {
+  if (g_pl_force >= 0 && g_pl_force < 7) {
     int f = g_pl_force;
     if (kPl3Eff[f] == 0.f) f = 1;                         // 256x256 / 224x256 do not exist with three planes
     if (N % kPlTiles[f].bn == 0) return f;
@@ -388,7 +390,7 @@ int pick_pl3_tile(int M, int N, int K) {
 }
 
 int pick_pl_tile(int M, int N, int K) {
-  if (g_pl_force >= 0 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
+  if (g_pl_force >= 0 && g_pl_force < 7 && N % kPlTiles[g_pl_force].bn == 0) return g_pl_force;
   // Short reductions (K <= 512: the 1x1 expand / reduce convs and their data gradients) and N = 128 are bound by the
   // epilogue's HBM traffic (residual / mask in, planes out), not by the matrix pipe.  The 128 x 128 tile needs 64 KB of
   // LDS, so TWO workgroups share a CU and one's epilogue overlaps the other's loads: measured with step-like operands
@@ -408,15 +410,69 @@ int pick_pl_tile(int M, int N, int K) {
   return best;
 }
 
+// ---- A-stationary form (igemm_pl_as.h): 1x1, stride 1, K = 64 / 128 / 256, three bf16 planes ---------------------
+bool pl_as_ok(const PlParams& p) {
+  if (!g_pl_as || g_pl_np != 3 || g_pl_f16) return false;
+  if (g_pl_force >= 0 && g_pl_force != 7) return false;            // a test / experiment asked for a tile of the table
+  const IgemmGeom& g = p.g;
+  if (g.KH != 1 || g.KW != 1 || g.mul != 1 || g.div != 1 || g.off != 0 || p.par) return false;
+  if (!(p.K == 64 || p.K == 128 || p.K == 256) || p.K != g.C || p.N % 64 != 0 || p.N < 4 * 64) return false;
+  if (p.C2h || (p.Yh && !p.Mi) || p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return false;
+  if ((long)p.M * g.ld * 2 >= 0x7FFFFFFFl) return false;          // 32-bit byte offsets of the fragment loads
+  return g_pl_force == 7 || (long)p.M * p.N >= (1l << 22);         // (small problems: the tile kernel's finer grid)
+}
+static int wg_slots_as() {   // workgroup slots of the chip for the A-stationary kernel: two per CU
+#ifdef STCAT_EMU
+  return 4;
+#else
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      slots = 2 * n;
+    else
+      slots = 512;
+  }
+  return slots;
+#endif
+}
+template <int KS>
+int launch_pl_as_ks(PlParams& p, hipStream_t st) {
+  constexpr int lds = KS * 3 * 32 * 64 + 4 * 16 * 68 * 4;
+  if (int rc = pl_prepare(igemm_pl_as_kernel<KS>, lds)) return rc;
+  // resident workgroups per CU: 2 at K = 256 (196 VGPRs), 3 at K = 128 (148), 4 at K = 64 (124)
+  const int rbs = cdiv(p.M, 64), chunks = p.N / 32, slots = wg_slots_as() / 2 * (KS == 8 ? 2 : (KS == 4 ? 3 : 4));
+  // whole rounds of the chip as whole row blocks (activation rows read once); the partial last round in quarter runs
+  int cpu = (chunks % 8 == 0) ? chunks / 4 : ((chunks % 4 == 0) ? chunks / 2 : chunks);   // (even: the epilogue works on chunk pairs)
+  // Rounds are counted on HALF the chip's slots: in the step these launches run beside another stream's (the second
+  // forward chain, the weight-gradient stream).  Measured at C3, same box, 10 steps each: whole-chip rounds 82.5 / 82.4 ms,
+  // "less than a round = whole row blocks" 82.7 / 82.2, half-chip rounds 82.2 / 82.0 (the tile kernel: 84.1).
+  int tier1 = (rbs / (slots / 2)) * (slots / 2);
+  if ((g_pl_debug & 0x400) && !(g_pl_debug & 8)) tier1 = 0;                          // (experiment: every row block in runs)
+  if ((g_pl_debug & 0x800) && !(g_pl_debug & 8)) tier1 = (rbs / slots) * slots;      // (experiment: whole-chip rounds)
+  if (rbs - tier1 == 0) cpu = chunks;
+  p.par = tier1;
+  p.k_chunk = cpu;
+  const int grid = tier1 + (rbs - tier1) * (chunks / cpu);
+  STCAT_LAUNCH((igemm_pl_as_kernel<KS>), dim3(grid), dim3(256), lds, st, p);
+  return launch_status();
+}
+int launch_pl_as(PlParams& p, hipStream_t st) {
+  if (p.K == 256) return launch_pl_as_ks<8>(p, st);
+  if (p.K == 128) return launch_pl_as_ks<4>(p, st);
+  return launch_pl_as_ks<2>(p, st);
+}
+
 int launch_pl_fwd(const PlParams& p_, hipStream_t st) {
   PlParams p = p_;
-  p.debug = g_pl_debug & 0xff;
+  p.debug = (g_pl_debug & 8) ? (g_pl_debug & 0xff) : (g_pl_debug & 0x3ff);   // (bits 8.. are the stagger ticks when bit 3 is set)
   p.stagger = (g_pl_debug & 8) ? (g_pl_debug >> 8) : 0;
   // mode f16x3p: the B operand (weight planes, plain or transposed) carries 2^wlog; gradient planes keep their 2^glog
   p.acc_mul = g_pl_f16 ? ldexpf(1.f, -g_f16_wlog) : 1.f;
   if (p.K % 32 != 0 || p.g.C % 32 != 0) return fail("plane GEMM: K and the channel count must be multiples of 32");
   if (p.g.div != 1 && p.g.div != 2 && p.g.div != 4) return fail("plane GEMM: stride must be 1, 2 or 4");
   if ((p.Ch == nullptr) != (p.Cl == nullptr)) return fail("plane GEMM: output planes go together");
+  if (pl_as_ok(p)) return launch_pl_as(p, st);
   // stride-2 data gradient on even dims: parity-class row order (igemm_pl.h, PlParams::par): 4 x tiles(M / 4)
   p.par = (p.g.div == 2 && p.g.mul == 1 && p.g.sgn == -1 && p.g.OH % 2 == 0 && p.g.OW % 2 == 0 && !(g_pl_debug & 4)) ? 1 : 0;
   const int Mrows = p.par ? p.M / 4 : p.M;
@@ -1201,14 +1257,15 @@ int stcat_temporal_map_argmax(const float* sted, const int* durations, int* out,
 
 // ---- plane-format backbone (mma mode 4): every tensor is a pair of bf16 planes (hi, lo) ------------------------
 int stcat_debug_force_pl_tile(int index) {
-  if (index < -1 || index > 6) return fail("debug_force_pl_tile: index must be -1 .. 6");
+  if (index < -1 || index > 7) return fail("debug_force_pl_tile: index must be -1 .. 7 (7 = the A-stationary kernel where it applies)");
   g_pl_force = index;
   return 0;
 }
 
 int stcat_debug_pl_flags(int flags) {
-  g_pl_debug = flags & ~4;             // bits 0,1,3.. : timing experiments (PlParams::debug, stagger)
+  g_pl_debug = flags & ~(4 | 128);     // bits 0,1,3.. : timing experiments (PlParams::debug, stagger)
   g_pl3_small = (flags & 4) ? 1 : 0;   // bit 2: three-plane short reductions on the two-workgroup 128 x 64 tile
+  g_pl_as = (flags & 128) ? 0 : 1;     // bit 7: the K <= 256 1x1 layers back on the two-stage tile kernel (A/B of igemm_pl_as.h)
   return 0;
 }
 

@@ -9,6 +9,7 @@
 #define STCAT_MFMA_32x32x2(a, b, c) emu_mfma_f32_32x32x2f32((a), (b), (c))
 #define STCAT_MFMA_BF16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
 #define STCAT_MFMA_F16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_f16((a), (b), (c))
+#define STCAT_MFMA_BF16_16x16x32(a, b, c) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
 #define STCAT_SCHED_GROUP(mask, n) ((void)0)
 #define STCAT_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   emu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
@@ -24,6 +25,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define STCAT_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define STCAT_MFMA_BF16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define STCAT_MFMA_F16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define STCAT_MFMA_BF16_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 // instruction-scheduler request: next group = n instructions of class mask (0x8 MFMA, 0x20 VMEM read, 0x100 DS read, ...)
 #define STCAT_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #define STCAT_LAUNCH(kernel, grid, block, shmem, stream, ...) \

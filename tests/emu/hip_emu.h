@@ -261,6 +261,27 @@ static inline f32x16 emu_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[l&15][8*(l>>4)+j] and B[8*(l>>4)+j][l&15], j < 8; D: col = l&15,
+// row = 4*(l>>4) + reg (cdna_hip_programming.md section 3)
+static inline f32x4 emu_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  emu::WaveState& w = emu::wave();
+  float (*sa)[8] = w.xa8;
+  float (*sb)[8] = w.xb8;
+  const int l = emu::lane();
+  for (int j = 0; j < 8; ++j) { sa[l][j] = (float)a[j]; sb[l][j] = (float)b[j]; }
+  emu::wave_sync();
+  const int col = l & 15, kg = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * kg + r;
+    float acc = c[r];
+    for (int h = 0; h < 4; ++h)
+      for (int j = 0; j < 8; ++j) acc = fmaf(sa[i + 16 * h][j], sb[col + 16 * h][j], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
 // v_mfma_f32_32x32x16_f16: the same lane mapping on fp16 operands
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static inline f32x16 emu_mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {

@@ -283,7 +283,17 @@ def _pl_conv(dev, big):
     _pl_conv_case(dev, 2, 9, 7, 128, 128, 1, 1, 0, relu=True, res=True, tile=6, mode="bf16x6p")
     _pl_conv_case(dev, 1, 10, 12, 128, 128, 1, 2, 0, relu=False, res=False, tile=6, mode="bf16x6p")
     _pl_conv_case(dev, 2, 7, 6, 64, 64, 3, 1, 1, relu=True, res=True, tile=6, wgrad=False, mode="bf16x6p")
+    # index 7: the A-stationary kernel (igemm_pl_as.h; three planes, 1x1 stride 1, K = 64 / 128 / 256, N >= 256 — forward
+    # where Cin is the short side, data gradient where Cout is): activation rows in registers, weight ring of K / 32
+    # slots, ragged last row block, residual planes, ReLU bit masks in and out, several units per row block
+    _pl_conv_case(dev, 2, 13, 11, 256, 256, 1, 1, 0, relu=True, res=True, tile=7, mode="bf16x6p")
+    _pl_conv_case(dev, 2, 9, 7, 128, 512, 1, 1, 0, relu=True, res=True, tile=7, mode="bf16x6p")
+    _pl_conv_case(dev, 1, 12, 12, 64, 256, 1, 1, 0, relu=False, res=False, tile=7, wgrad=False, mode="bf16x6p")
+    _pl_conv_case(dev, 3, 7, 7, 512, 128, 1, 1, 0, relu=True, res=False, tile=7, mode="bf16x6p")      # (data gradient: K = 128, N = 512)
     if big:
+        _pl_conv_case(dev, 4, 28, 28, 256, 1024, 1, 1, 0, relu=True, res=True, mode="bf16x6p")           # layer3 conv3 / conv1 dgrad
+        _pl_conv_case(dev, 4, 28, 28, 1024, 256, 1, 1, 0, relu=True, res=False, mode="bf16x6p")
+        _pl_conv_case(dev, 2, 56, 56, 128, 512, 1, 1, 0, relu=True, res=True, mode="bf16x6p")
         for m3 in ("bf16x6p", "f16x3p"):
             _pl_conv_case(dev, 4, 28, 28, 256, 256, 3, 1, 1, relu=True, res=False, mode=m3)
             _pl_conv_case(dev, 4, 28, 28, 512, 256, 3, 2, 1, relu=True, res=False, mode=m3)
