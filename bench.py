@@ -77,6 +77,23 @@ def _flops(name, a):
     return 0.0
 
 
+def _alg_elems(name, a):
+    """operand ELEMENTS a plane conv forward / data-gradient launch has to move once (SURVEY.md section 8d's algorithmic
+    bytes = this x 4 for fp32 tensors, x 6 for the three-plane format): gathered operand + weights + output (+ the
+    residual / `add` operand when present; bit masks are 1/48 of a plane set and not counted)"""
+    if name == "stcat_pl_conv_fwd":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[12:21]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        e = n * H * W * Cin + n * OH * OW * Cout + Cout * KH * KW * Cin
+        return e + (n * OH * OW * Cout if a[6] else 0)
+    if name == "stcat_pl_conv_dgrad":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[15:24]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        e = n * OH * OW * Cout + n * H * W * Cin + Cout * KH * KW * Cin
+        return e + (n * H * W * Cin if a[4] else 0) + (n * H * W * Cin if a[12] else 0)
+    return 0
+
+
 def source_sha() -> str:
     """fingerprint of everything a PMC replay depends on: the kernel sources, the C ABI and this file"""
     import hashlib
@@ -108,7 +125,7 @@ def _pmc_traffic(entry: str, mma: str):
     doc = json.load(open(files[-1]))
     k = doc["kernels"]
     if "igemm_pl_fwd" in entry:
-        pick = lambda n: "igemm_pl_fwd_kernel" in n  # noqa: E731
+        pick = lambda n: "igemm_pl_fwd_kernel" in n or "igemm_pl_as_kernel" in n  # noqa: E731
     elif "igemm_bs_fwd" in entry:
         pick = lambda n: "igemm_bs_fwd_kernel<128" in n or "igemm_bs_fwd_kernel<256" in n  # noqa: E731
     else:
@@ -121,7 +138,9 @@ def _pmc_traffic(entry: str, mma: str):
     n = sum(a for a, _, _ in sel)
     if not n:
         return None
-    return {"MB_per_launch": round(sum(a * (r + w) for a, r, w in sel) / n, 1),
+    steps_in_pass = doc.get("steps_traced") or 0
+    return {"launches_per_step_in_pmc_pass": (n / steps_in_pass) if steps_in_pass else None,
+            "MB_per_launch": round(sum(a * (r + w) for a, r, w in sel) / n, 1),
             "read_MB_per_launch": round(sum(a * r for a, r, _ in sel) / n, 1),
             "write_MB_per_launch": round(sum(a * w for a, _, w in sel) / n, 1), **_replay_tag(files[-1], doc),
             "note": "all launches of the kernel family in one step; PMC, separate FETCH_SIZE / WRITE_SIZE passes"}
@@ -176,7 +195,7 @@ class LaunchProfiler:
             e0.record()
             self._orig(name, *args)
             e1.record()
-            self.records.append((name, _flops(name, args), e0, e1, _shape_key(name, args)))
+            self.records.append((name, _flops(name, args), e0, e1, _shape_key(name, args), _alg_elems(name, args)))
 
         _lib.call = timed
         import stcat_amd.ops as ops_mod
@@ -190,12 +209,13 @@ class LaunchProfiler:
     def summary(self):
         agg = {}
         self.shapes = {}
-        for name, fl, e0, e1, key in self.records:
+        for name, fl, e0, e1, key, el in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0, "elems": 0})
             d["launches"] += 1
             d["ms"] += ms
             d["flop"] += fl
+            d["elems"] += el
             if key:
                 d = self.shapes.setdefault(key, {"launches": 0, "ms": 0.0, "flop": 0.0})
                 d["launches"] += 1
@@ -428,8 +448,9 @@ def main():
         if args.mma in ("bf16x3p", "bf16x6p", "f16x3p") and "stcat_pl_conv_fwd" in agg and "stcat_pl_conv_dgrad" in agg:
             a, b = agg["stcat_pl_conv_fwd"], agg["stcat_pl_conv_dgrad"]
             fam = {k: v for k, v in agg.items() if k not in ("stcat_pl_conv_fwd", "stcat_pl_conv_dgrad")}
-            fam["igemm_pl_fwd_kernel (stcat_pl_conv_fwd + stcat_pl_conv_dgrad)"] = {
-                "launches": a["launches"] + b["launches"], "ms": a["ms"] + b["ms"], "flop": a["flop"] + b["flop"]}
+            fam["igemm_pl_fwd_kernel + igemm_pl_as_kernel (stcat_pl_conv_fwd + stcat_pl_conv_dgrad)"] = {
+                "launches": a["launches"] + b["launches"], "ms": a["ms"] + b["ms"], "flop": a["flop"] + b["flop"],
+                "elems": a.get("elems", 0) + b.get("elems", 0)}
         elif args.mma != "f32" and "stcat_conv_fwd" in agg and "stcat_conv_dgrad" in agg:
             a, b = agg["stcat_conv_fwd"], agg["stcat_conv_dgrad"]
             fam = {k: v for k, v in agg.items() if k not in ("stcat_conv_fwd", "stcat_conv_dgrad")}
@@ -465,13 +486,24 @@ def main():
                 "duration_note": "achieved / frac use the ISOLATED per-launch duration (instrumented step on one stream: "
                                  "kernels run one at a time); co_scheduled = the same launches inside the three-stream "
                                  "step, where kernels of other streams share the CUs; rocprofv3 kernel stats of both "
-                                 "schedules: profiles/r04_bench_c3_kernel_stats_{serial,bf16x6p}.csv",
+                                 "schedules: profiles/r05_bench_c3_kernel_stats_{serial,bf16x6p}.csv",
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
         tr = _pmc_traffic(dom, args.mma)
         # `traffic`: HBM bytes per launch of the dominant kernel family (PMC FETCH_SIZE / WRITE_SIZE passes, see the
         # detail entry for the split and the source file); `achieved`'s counterpart in bytes: algorithmic operand bytes
         roof["traffic"] = int(tr["MB_per_launch"] * 1e6) if tr else None
         roof["traffic_detail"] = tr
+        # bytes per STEP of the family, next to what the contractions have to move at least
+        # (every operand once: fp32 tensors = 4 bytes per element, the three-plane format the kernels use = 6)
+        el = d.get("elems", 0)
+        planes = {"bf16x3p": 2, "bf16x6p": 3, "f16x3p": 2}.get(args.mma)
+        roof["algorithmic_GB_per_step_fp32"] = round(el * 4 / 1e9, 2) if el else None
+        roof["algorithmic_GB_per_step_planes"] = round(el * 2 * planes / 1e9, 2) if el and planes else None
+        if tr and tr.get("launches_per_step_in_pmc_pass"):
+            gb = tr["MB_per_launch"] * tr["launches_per_step_in_pmc_pass"] / 1e3
+            roof["traffic_GB_per_step"] = round(gb, 2)
+            roof["traffic_over_algorithmic_planes"] = (round(gb / (el * 2 * planes / 1e9), 3) if el and planes else None)
+            roof["traffic_over_algorithmic_fp32"] = round(gb / (el * 4 / 1e9), 3) if el else None
         roof["mfma_util"] = _pmc_mfma_util(args.mma)
         mm = sum(v["flop"] for v in agg_iso.values())
         mm_ms = sum(v["ms"] for v in agg_iso.values() if v["flop"] > 0)

@@ -119,6 +119,14 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
                         const float* mask_scale, void* dxh, void* dxl,
                         void* dx2h, void* dx2l, const float* dx2_scale, int n, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, void* stream);
+/* Block-boundary data gradient of a Bottleneck with a strided downsample branch (torchvision Bottleneck.forward:
+ * out = conv3(..) + downsample(x); call site models/vision_model/backbone.py:115-119): dx = [ybits](g . w1^T +
+ * scatter(addc)), addc [n][ceil(H/add_stride)][ceil(W/add_stride)][Cin] = the downsample conv's data gradient on its own
+ * coarse grid (a plain 1x1 GEMM through stcat_pl_conv_dgrad with stride 1), placed at pixels (add_stride i, add_stride j).
+ * 1x1, stride 1, bf16-plane modes; ybits / mask_scale as in stcat_pl_conv_dgrad. */
+int stcat_pl_conv_dgrad_cadd(const void* gh, const void* gl, const void* th, const void* tl, const void* addch,
+                             const void* addcl, int add_stride, const unsigned char* ybits, const float* mask_scale,
+                             void* dxh, void* dxl, int n, int H, int W, int Cin, int Cout, void* stream);
 /* dw (fp32 OHWI, caller-zeroed) += row_scale[co] * sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0.
  * row_scale (optional, [Cout]): a FrozenBN scale folded out of g — dz * scale is never materialised */
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,

@@ -69,6 +69,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_pl_conv_fwd": "pppppppppppp" + "iiiiiiiiii" + "s",
     "stcat_pl_conv_dgrad": "ppppppppppppppp" + "iiiiiiiii" + "s",
+    "stcat_pl_conv_dgrad_cadd": "pppppp" + "i" + "pppp" + "iiiii" + "s",
     "stcat_pl_conv_wgrad": "pppppp" + "iiiiiiiii" + "s",
     "stcat_pl_maxpool3x3s2": "pppiiiis",
     "stcat_pl_split": "pppls",

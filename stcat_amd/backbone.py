@@ -28,6 +28,7 @@ FORWARD_CHAINS = 1 if os.environ.get("STCAT_NO_FORWARD_CHAINS") else int(os.envi
 # the same for the data-gradient chain of the backward pass: measured neutral next to the weight-gradient stream
 # (86.9 vs 86.9 ms per C3 step), so opt-in
 BACKWARD_CHAINS = bool(os.environ.get("STCAT_BACKWARD_CHAINS"))
+COARSE_ADD = not os.environ.get("STCAT_NO_COARSE_ADD")   # downsample-branch gradient added from its own grid (round 5)
 
 
 def _chain_streams(dev, k):
@@ -381,6 +382,24 @@ class _BackboneFnPl(Function):
                         ops.pl_conv_dgrad_raw(g.frames(a, b), wt_, shp, k, stride, pad, **kw)
             return dx
 
+        def dgrad_cadd(g, wt_, in_shape, addc, add_stride, mask_y):
+            if chains is None:
+                return ops.pl_conv_dgrad_cadd_raw(g, wt_, in_shape, addc, add_stride, mask_y=mask_y)
+            dx = ops.Planes.empty(g.t, *in_shape)
+            dx.t.record_stream(fork.side)
+            if ops.L.RECORDER is not None:
+                ops.L.RECORDER.keep.append(dx.t)
+            for ci, (a, b) in enumerate(chains):
+                shp = (b - a,) + tuple(in_shape[1:])
+                args = (g.frames(a, b), wt_, shp, addc.frames(a, b), add_stride)
+                kw = dict(mask_y=mask_y.frames(a, b), out=dx.frames(a, b))
+                if ci == 0:
+                    ops.pl_conv_dgrad_cadd_raw(*args, **kw)
+                else:
+                    with torch.cuda.stream(fork.side):
+                        ops.pl_conv_dgrad_cadd_raw(*args, **kw)
+            return dx
+
         blk, x, o1, o2, y, _, (s1, s2, s3, sd) = tape[-1]
         # top of the stack (y is the fp32 layer4 output): dz = dy * [y > 0] as planes
         _, dz = ops.pl_act_bwd_raw(dy.contiguous(), y, None, want_g=False, want_res=True, relu=True)
@@ -414,7 +433,14 @@ class _BackboneFnPl(Function):
             if not need_dx:
                 break
             # block boundary: x is the ReLU output of the block below; its dz comes out of this epilogue
-            if wd is not None:
+            if wd is not None and blk.stride == 2 and COARSE_ADD and x.mask is not None:
+                # round 5: the downsample conv's data gradient stays on ITS grid (a plain 1x1 GEMM on a quarter of the
+                # pixels); conv1's data gradient adds it on the stride-2 lattice in its epilogue (round 4 scattered it
+                # into a full-resolution tensor, 3/4 zeros, and read that back: 0.92 ms per launch at layer3.0 / layer4.0)
+                n_, H_, W_, C_ = x.shape
+                coarse = dgrad(dz, _wt(wd), (n_, dz.shape[1], dz.shape[2], C_), 1, 1, 0)
+                dz = dgrad_cadd(g1, _wt(w1), x.shape, coarse, blk.stride, x)
+            elif wd is not None:
                 part = dgrad(dz, _wt(wd), x.shape, 1, blk.stride, 0)
                 dz = dgrad(g1, _wt(w1), x.shape, 1, 1, 0, add=part, out=part, mask_y=x)
             else:

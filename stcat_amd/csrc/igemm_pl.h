@@ -63,6 +63,11 @@ struct PlParams {
                                         // (0 = off); set by the launcher for many-round, epilogue-heavy launches
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
                                         // 2 = epilogue without global loads / stores
+  int radd_div, radd_h, radd_w;         // fwd kernel, round 5: the residual / `add` planes live on the COARSE grid of a stride-
+                                        // radd_div conv ([n][radd_h][radd_w][ldr]) and are added at the output pixels on its
+                                        // lattice only ((oh, ow) multiples of radd_div; nothing elsewhere): the data gradient
+                                        // of a bottleneck's stride-2 downsample conv never has to be scattered into a
+                                        // full-resolution tensor that is 3/4 zeros (0 / 1: plain row-for-row residual)
   IgemmGeom g;
 };
 
@@ -395,8 +400,18 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
       q.m[ps] = m;
       if (mrow < Mc && !(p.debug & (2 | 32))) {     // (debug 32: no epilogue loads)
         if (p.Rh) {
+          long mr = m;
+          if (p.radd_div > 1) {                     // coarse-grid residual: only the lattice pixels have one
+            const int nb = stcat_fastdiv(m, g.mg_ohw, g.sh_ohw), rem = m - nb * g.OH * g.OW;
+            const int oh = stcat_fastdiv(rem, g.mg_ow, g.sh_ow), ow = rem - oh * g.OW;
+            const int dm = p.radd_div - 1, ds = p.radd_div == 2 ? 1 : 2;
+            mr = ((oh | ow) & dm) ? -1 : ((long)nb * p.radd_h + (oh >> ds)) * p.radd_w + (ow >> ds);
+          }
           STCAT_UNROLL
-          for (int pi = 0; pi < NP; ++pi) q.r[ps][pi] = STCAT_LOAD_STREAM(reinterpret_cast<const bf16x8*>(Rp[pi] + (long)m * p.ldr + n));
+          for (int pi = 0; pi < NP; ++pi) {
+            if (mr >= 0) q.r[ps][pi] = STCAT_LOAD_STREAM(reinterpret_cast<const bf16x8*>(Rp[pi] + mr * p.ldr + n));
+            else { STCAT_UNROLL for (int e = 0; e < 8; ++e) q.r[ps][pi][e] = (__bf16)0.f; }
+          }
         }
         if (p.Mi) q.bits[ps] = p.Mi[((long)m * p.ldc + n) >> 3];
       }

@@ -417,7 +417,7 @@ bool pl_as_ok(const PlParams& p) {
   const IgemmGeom& g = p.g;
   if (g.KH != 1 || g.KW != 1 || g.mul != 1 || g.div != 1 || g.off != 0 || p.par) return false;
   if (!(p.K == 64 || p.K == 128 || p.K == 256) || p.K != g.C || p.N % 64 != 0 || p.N < 4 * 64) return false;
-  if (p.C2h || (p.Yh && !p.Mi) || p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return false;
+  if (p.C2h || (p.Yh && !p.Mi) || p.radd_div > 1 || p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return false;
   if ((long)p.M * g.ld * 2 >= 0x7FFFFFFFl) return false;          // 32-bit byte offsets of the fragment loads
   return g_pl_force == 7 || (long)p.M * p.N >= (1l << 22);         // (small problems: the tile kernel's finer grid)
 }
@@ -1316,6 +1316,36 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
   return launch_pl_fwd(p, (hipStream_t)stream);
 }
 
+// The block-boundary data gradient of a bottleneck WITH a strided downsample branch (torchvision Bottleneck: out =
+// conv3(..) + downsample(x), models/vision_model/backbone.py:115-119): dx = [ybits] (g . W1^T + scatter(addc)) where addc
+// [n, ceil(H / add_stride), ceil(W / add_stride), Cin] is the downsample conv's data gradient on ITS OWN (coarse) grid —
+// a plain 1x1 GEMM — and scatter() places row (i, j) at pixel (add_stride i, add_stride j).  Round 4 materialised the
+// scattered tensor (3/4 zeros: 0.92 ms per launch at layer3.0 / layer4.0) and read it back as `add`.
+int stcat_pl_conv_dgrad_cadd(const void* gh, const void* gl, const void* th, const void* tl, const void* addch,
+                             const void* addcl, int add_stride, const unsigned char* ybits, const float* mask_scale,
+                             void* dxh, void* dxl, int n, int H, int W, int Cin, int Cout, void* stream) {
+  if (Cout % 32 != 0 || Cin % 64 != 0) return fail("pl_conv_dgrad_cadd: need Cout %% 32 == 0 and Cin %% 64 == 0 (%d, %d)", Cout, Cin);
+  if (add_stride != 2 && add_stride != 4) return fail("pl_conv_dgrad_cadd: add_stride must be 2 or 4");
+  if (!addch || !addcl) return fail("pl_conv_dgrad_cadd: the coarse-grid operand is required");
+  if (g_mma_mode_raw < 4) return fail("pl_conv_dgrad_cadd: plane modes only");
+  PlParams p = {};
+  p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)th; p.Bl = (const __bf16*)tl;
+  p.Ch = (__bf16*)dxh; p.Cl = (__bf16*)dxl; p.Rh = (const __bf16*)addch; p.Rl = (const __bf16*)addcl;
+  p.Mi = ybits; p.mscale = mask_scale;
+  p.radd_div = add_stride; p.radd_h = (H - 1) / add_stride + 1; p.radd_w = (W - 1) / add_stride + 1;
+  p.a_bytes = plane_bytes((long)n * H * W * Cout); p.b_bytes = plane_bytes((long)Cout * Cin);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_dgrad_cadd: a plane exceeds 2 GB");
+  p.ldb = Cout; p.b_tap_stride = (unsigned)((long)Cin * Cout);
+  p.M = n * H * W; p.N = Cin; p.K = Cout; p.ldc = Cin; p.ldr = Cin; p.relu = 0;
+  IgemmGeom q;
+  q.H = H; q.W = W; q.C = Cout; q.ld = Cout; q.OH = H; q.OW = W; q.KH = 1; q.KW = 1;
+  q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
+  stcat_fastdiv_magic(W, &q.mg_ow, &q.sh_ow);
+  stcat_fastdiv_magic(H * W, &q.mg_ohw, &q.sh_ohw);
+  p.g = q;
+  return launch_pl_fwd(p, (hipStream_t)stream);
+}
+
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
                         int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
@@ -1533,6 +1563,7 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_temporal_map_argmax),
     STCAT_PLAN_FN(stcat_pl_conv_fwd),
     STCAT_PLAN_FN(stcat_pl_conv_dgrad),
+    STCAT_PLAN_FN(stcat_pl_conv_dgrad_cadd),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad),
     STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),
     STCAT_PLAN_FN(stcat_pl_split),

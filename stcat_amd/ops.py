@@ -1419,6 +1419,20 @@ def pl_conv_dgrad_raw(g: Planes, wt: Planes, in_shape, k, stride, pad, add: Opti
     return dx if scale2 is None else (dx, dx2)
 
 
+def pl_conv_dgrad_cadd_raw(g: Planes, wt: Planes, in_shape, addc: Planes, add_stride: int, mask_y: Optional[Planes] = None,
+                           mask_scale=None, out: Optional[Planes] = None) -> Planes:
+    """1x1 stride-1 data gradient + the COARSE-grid operand `addc` [n, ceil(H/s), ceil(W/s), Cin] scattered onto the
+    stride-s lattice (the downsample branch's gradient, never materialised at full resolution) + bit-mask ReLU backward"""
+    n, H, W, Cin = in_shape
+    Cout = g.shape[-1]
+    dx = Planes.empty(g.t, n, H, W, Cin) if out is None else out
+    bits = mask_y.mask if mask_y is not None else None
+    assert mask_y is None or bits is not None, "the coarse-add form takes the ReLU mask as bits"
+    L.call("stcat_pl_conv_dgrad_cadd", g.h, g.l, wt.h, wt.l, addc.h, addc.l, int(add_stride), L._ptr(bits),
+           L._ptr(mask_scale), dx.h, dx.l, n, H, W, Cin, Cout, L.stream_of(g.t))
+    return dx
+
+
 def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad, row_scale=None, out=None) -> torch.Tensor:
     """row_scale [Cout]: dW[co] *= row_scale[co] — a FrozenBN scale folded out of g (g = dz, not dz * scale).
     out: a ZEROED OHWI buffer to accumulate into (a data-parallel gradient bucket) instead of a fresh one."""

@@ -312,6 +312,42 @@ def _pl_conv(dev, big):
 
 
 @both
+def _pl_dgrad_coarse_add(dev, big):
+    """stcat_pl_conv_dgrad_cadd: the block-boundary data gradient with the downsample branch's gradient taken from its own
+    (stride-2) grid == the round-4 form that scatters it into a full-resolution tensor first; odd H / W, two and three planes"""
+    old_mode = L.get_mma_mode()
+    try:
+        for mode in ("bf16x6p", "bf16x3p"):
+            L.set_mma_mode(mode)
+            for (n, H, W, Cin, Cout) in ((2, 9, 7, 128, 64), (1, 10, 12, 64, 128)) + (((4, 28, 28, 512, 256),) if big else ()):
+                OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                g = rnd(n, H, W, Cout, seed=11).to(dev)                  # gradient at conv1's output
+                w = rnd(Cout, 1, 1, Cin, seed=12, scale=Cin ** -0.5).to(dev)
+                coarse = rnd(n, OH, OW, Cin, seed=13).to(dev)           # the downsample branch's gradient on its grid
+                y = rnd(n, H, W, Cin, seed=14).to(dev)
+                _, wt = ops.WeightPlanes().refresh([w], transposed=True)
+                wt = wt[w.data_ptr()]
+                gp, cp = ops.pl_split(g), ops.pl_split(coarse)
+                yp = ops.pl_split(y)
+                yp.mask = ((y.reshape(-1, Cin // 8, 8) > 0).to(torch.int32)
+                           << torch.arange(8, device=y.device).to(torch.int32)).sum(-1).to(torch.uint8)
+                full = torch.zeros(n, H, W, Cin, device=dev)
+                full[:, ::2, ::2] = ops.pl_join(cp)
+                want = ops.pl_conv_dgrad_raw(gp, wt, (n, H, W, Cin), 1, 1, 0, add=ops.pl_split(full), mask_y=yp)
+                L.call("stcat_debug_force_pl_tile", 3 if not big else -1)
+                try:
+                    got = ops.pl_conv_dgrad_cadd_raw(gp, wt, (n, H, W, Cin), cp, 2, mask_y=yp)
+                finally:
+                    L.call("stcat_debug_force_pl_tile", -1)
+                ref = (g.cpu().reshape(-1, Cout).double() @ w.cpu().reshape(Cout, Cin).double()).reshape(n, H, W, Cin)
+                ref = (ref + full.cpu().double()) * (y.cpu() > 0)
+                close(ops.pl_join(got), ref.float(), 2e-5 if mode == "bf16x6p" else 2e-4, f"coarse add [{mode}] vs fp64")
+                close(ops.pl_join(got), ops.pl_join(want), 1e-6, f"coarse add [{mode}] vs scattered add")
+    finally:
+        L.set_mma_mode(old_mode)
+
+
+@both
 def _pl_maxpool(dev, big):
     n, H, C = (2, 10, 64) if not big else (4, 112, 64)
     x = rnd(n, C, H, H, seed=1)

@@ -13,7 +13,7 @@ from stcat_amd.pipeline import SyntheticText, build_model  # noqa: E402
 
 dev = torch.device("cuda:0")
 _lib.load()
-_lib.set_mma_mode(sys.argv[1] if len(sys.argv) > 1 else "bf16x3p")
+_lib.set_mma_mode(sys.argv[1] if len(sys.argv) > 1 else "bf16x6p")
 T, res, L = synth.CONFIGS["C3"]
 model, criterion, wd = build_model(None, SyntheticText(synth.synth_text(L)))
 model.train()
