@@ -272,3 +272,4 @@ __global__ void __launch_bounds__(256, 2) igemm_pl_as_kernel(PlParams p) {
 #undef STCAT_AS_READ
 #undef STCAT_AS_MMA
 }
+
