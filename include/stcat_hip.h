@@ -196,6 +196,19 @@ int stcat_linear_fwd_drop(const float* x, const float* w, const float* bias, con
  * dropout(relu(.)) output (positive <=> ReLU passed and the element was kept) and mask_gain = 1 / (1 - p). */
 int stcat_linear_dgrad_mask(const float* g, const float* w, const float* add, const float* wt, const float* mask_y,
                             float mask_gain, float* dx, int M, int N, int K, int ldg, int lddx, void* stream);
+/* Up to eight INDEPENDENT skinny Linear problems of one shape (M <= 128 rows: the [T,256] query states of the decoders)
+ * in ONE launch — the seven input projections of a box-decoder layer's self-attention (sa_qcontent / sa_qtime / sa_qpos /
+ * sa_kcontent / sa_ktime / sa_kpos / sa_v, query_decoder.py:329-338), the three in-projections of nn.MultiheadAttention
+ * (:341), ca_qcontent / ca_qpos / ca_qpos_sine (:360-369) — and the matching data / weight gradients.  Accumulating forms:
+ * y_j += x_j w_j^T + b_j, dx_j += g_j w_j (+ add_j), dw_j += g_j^T x_j (db_j += column sums) onto outputs that hold the
+ * value to add to (zeros from the caller's arena); problems may share an output (q = Wqc tgt + Wqt time + Wqp pos).
+ * Unused slots are NULL; split-bf16 modes only. */
+int stcat_linear_fwd_multi(int n, const float* x0, const float* x1, const float* x2, const float* x3, const float* x4, const float* x5, const float* x6, const float* x7, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5, const float* w6, const float* w7, const float* b0, const float* b1, const float* b2, const float* b3, const float* b4, const float* b5, const float* b6, const float* b7,
+                           float* y0, float* y1, float* y2, float* y3, float* y4, float* y5, float* y6, float* y7, int M, int N, int K, void* stream);
+int stcat_linear_dgrad_multi(int n, const float* g0, const float* g1, const float* g2, const float* g3, const float* g4, const float* g5, const float* g6, const float* g7, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5, const float* w6, const float* w7, const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, const float* a5, const float* a6, const float* a7,
+                             float* d0, float* d1, float* d2, float* d3, float* d4, float* d5, float* d6, float* d7, int M, int N, int K, void* stream);
+int stcat_linear_wgrad_multi(int n, const float* g0, const float* g1, const float* g2, const float* g3, const float* g4, const float* g5, const float* g6, const float* g7, const float* x0, const float* x1, const float* x2, const float* x3, const float* x4, const float* x5, const float* x6, const float* x7, float* dw0, float* dw1, float* dw2, float* dw3, float* dw4, float* dw5, float* dw6, float* dw7,
+                             float* db0, float* db1, float* db2, float* db3, float* db4, float* db5, float* db6, float* db7, int M, int N, int K, void* stream);
 /* dw[N,K] (caller-zeroed) += g[M,N]^T . x[M,K];  N % 64 == 0, K % 64 == 0.  db (may be NULL; caller-zeroed,
  * needs ldg == N) += column sums of g — the bias gradient of the same nn.Linear, summed inside the launch */
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,

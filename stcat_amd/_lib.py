@@ -36,6 +36,9 @@ SIGNATURES: Dict[str, str] = {
     "stcat_linear_dgrad": "pppppiiiiis",
     "stcat_linear_fwd_acc": "pppppiiiiiis",
     "stcat_linear_dgrad_acc": "ppppiiiiis",
+    "stcat_linear_fwd_multi": "i" + "p" * 32 + "iii" + "s",
+    "stcat_linear_dgrad_multi": "i" + "p" * 32 + "iii" + "s",
+    "stcat_linear_wgrad_multi": "i" + "p" * 32 + "iii" + "s",
     "stcat_linear_fwd_drop": "ppppp" + "iiiiiii" + "fllp" + "s",
     "stcat_linear_dgrad_mask": "ppppp" + "f" + "p" + "iiiii" + "s",
     "stcat_linear_wgrad": "ppppiiiiis",

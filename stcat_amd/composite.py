@@ -139,6 +139,15 @@ def _wgrad(g, x2, dw, db, M, N, K):
         L.call("stcat_linear_wgrad", *args, L.stream_of(g))
 
 
+def _wgrad_multi(gs, xs, dws, dbs, M, N, K):
+    """the weight gradients of up to eight same-shape skinny Linears as ONE launch (ops.linear_wgrad_multi), deferred to the
+    weight-gradient stream like _wgrad"""
+    if _BATCH and _BATCH[-1] is not None and DEFER_WGRADS:
+        _BATCH[-1].append((("multi", list(gs), list(xs), list(dws), list(dbs), M, N, K), gs[0], xs[0]))
+    else:
+        ops.linear_wgrad_multi(gs, xs, dws, dbs, M, N, K)
+
+
 def wgrad_flush(like: torch.Tensor) -> None:
     """issue what the innermost batch has collected so far (end of a decoder layer inside its node's batch)"""
     if not _BATCH or not _BATCH[-1]:       # (no batch, an empty one, or a None frame: launches went out directly)
@@ -149,9 +158,15 @@ def wgrad_flush(like: torch.Tensor) -> None:
     with wg:
         st = L.stream_of(like)
         for args, _, _ in pending:
-            L.call("stcat_linear_wgrad", *args, st)
-    for _, g, x2 in pending:
-        wg.keep(g, x2)
+            if args[0] == "multi":
+                ops.linear_wgrad_multi(*args[1:])
+            else:
+                L.call("stcat_linear_wgrad", *args, st)
+    for args, g, x2 in pending:
+        if args[0] == "multi":
+            wg.keep(*args[1], *args[2])
+        else:
+            wg.keep(g, x2)
     _DIRTY[0] = True
 
 
@@ -581,24 +596,42 @@ class BoxDecoderFn(Function):
                 sine_q = ops.ew2d(L.EW_MUL, sine_h, qsc)
             st["sine_h"] = sine_h
             # ---- the layer: self-attention over the T queries :329-345
-            t, _ = _lin_f(out, Wqc, bqc)
-            t, _ = _lin_f(time_embed, Wqt, bqt, res=t)
-            q, _ = _lin_f(qpos, Wqp, bqp, res=t)
-            t, _ = _lin_f(out, Wkc, bkc)
-            t, _ = _lin_f(time_embed, Wkt, bkt, res=t)
-            k, _ = _lin_f(qpos, Wkp, bkp, res=t)
-            v, _ = _lin_f(out, Wv, bv)
-            qp, _ = _lin_f(q, W_in[:D], B_in[:D])
-            kp_, _ = _lin_f(k, W_in[D:2 * D], B_in[D:2 * D])
-            vp, _ = _lin_f(v, W_in[2 * D:], B_in[2 * D:])
+            mg = ops.linear_multi_ok(T, D, D, out)     # grouped launches for the independent skinny projections (round 5)
+            if mg:
+                # q = Wqc out + Wqt time + Wqp pos, k likewise, v = Wv out: seven problems, three (zeroed) outputs, ONE launch
+                q, k, v = ops._zeros(out, T, D), ops._zeros(out, T, D), ops._zeros(out, T, D)
+                ops.linear_fwd_multi([out, time_embed, qpos, out, time_embed, qpos, out], [Wqc, Wqt, Wqp, Wkc, Wkt, Wkp, Wv],
+                                     [bqc, bqt, bqp, bkc, bkt, bkp, bv], [q, q, q, k, k, k, v], T, D, D)
+                qp, kp_, vp = ops._zeros(out, T, D), ops._zeros(out, T, D), ops._zeros(out, T, D)
+                ops.linear_fwd_multi([q, k, v], [W_in[:D], W_in[D:2 * D], W_in[2 * D:]],
+                                     [B_in[:D], B_in[D:2 * D], B_in[2 * D:]], [qp, kp_, vp], T, D, D)
+            else:
+                t, _ = _lin_f(out, Wqc, bqc)
+                t, _ = _lin_f(time_embed, Wqt, bqt, res=t)
+                q, _ = _lin_f(qpos, Wqp, bqp, res=t)
+                t, _ = _lin_f(out, Wkc, bkc)
+                t, _ = _lin_f(time_embed, Wkt, bkt, res=t)
+                k, _ = _lin_f(qpos, Wkp, bkp, res=t)
+                v, _ = _lin_f(out, Wv, bv)
+                qp, _ = _lin_f(q, W_in[:D], B_in[:D])
+                kp_, _ = _lin_f(k, W_in[D:2 * D], B_in[D:2 * D])
+                vp, _ = _lin_f(v, W_in[2 * D:], B_in[2 * D:])
             (a, _), st["att"] = _f(ops.MhaSelfFn, _T, qp[None], kp_[None], vp[None], None, hd ** -0.5, False, False, p)
             tgt1, st["o1"] = _outln_f(a[0], Wo, bo, out, g1, be1, p)
             st["sa_in"] = (out, qpos, q, k, v)
             # ---- time-aligned cross-attention :355-432
-            qc, _ = _lin_f(tgt1, Wcq, bcq)
-            if first:                                                                        # :360-366
-                qc, _ = _lin_f(qpos, Wcqp, bcqp, res=qc)
-            qs, st["x_qs"] = _lin_f(sine_q, Wqs, bqs)                                        # :369
+            if mg and sine_q.is_contiguous():
+                qc, qs = ops._zeros(out, T, D), ops._zeros(out, T, D)
+                xs_, ws_, bs_, ys_ = [tgt1, sine_q], [Wcq, Wqs], [bcq, bqs], [qc, qs]
+                if first:                                                                    # :360-366
+                    xs_.append(qpos); ws_.append(Wcqp); bs_.append(bcqp); ys_.append(qc)
+                ops.linear_fwd_multi(xs_, ws_, bs_, ys_, T, D, D)
+                st["x_qs"] = sine_q
+            else:
+                qc, _ = _lin_f(tgt1, Wcq, bcq)
+                if first:                                                                    # :360-366
+                    qc, _ = _lin_f(qpos, Wcqp, bcqp, res=qc)
+                qs, st["x_qs"] = _lin_f(sine_q, Wqs, bqs)                                    # :369
             kci, kpi, vvi = nxt
             lane.sync_main()                       # this layer's memory-side projections (queued a layer ago) are in
             if i + 1 < nl:
@@ -696,27 +729,75 @@ class BoxDecoderFn(Function):
             d_mem, dWmk, dbmk, _ = _lin_b(dk1, x_mem, Wmk, need_dx=need_mem, add=d_mem)
             d_mem, dWmv, dbmv, _ = _lin_b(dvv_i, x_mem, Wmv, need_dx=need_mem, add=d_mem)
             _, dWmp, dbmp, _ = _lin_b(_add(dk1, dk2) if first else dk2, x_pos, Wmp, need_dx=False)
-            d_sine_q, dWqs, dbqs, _ = _lin_b(dqs, st["x_qs"], Wqs, need_dx=(not first) or need_anchor)
+            mg = ops.linear_multi_ok(T, D, D, like) and st["x_qs"].is_contiguous()
+            zTD = lambda: ops._zeros(like, T, D)        # noqa: E731
+            zW = lambda: (ops._zeros(like, D, D), ops._zeros(like, D))     # noqa: E731
+            nd = not first                              # layer 0's input state is the constant zero tensor
             d_qpos = None
             dWcqp = dbcqp = None
-            if first:
-                d_qpos, dWcqp, dbcqp, _ = _lin_b(dqc, qpos, Wcqp)
-            d_tgt1, dWcq, dbcq, _ = _lin_b(dqc, st["tgt1"], Wcq, add=d_tgt1_res)
+            if mg:
+                # the independent data / weight gradients of the layer's skinny projections in grouped launches
+                # (ops.linear_*_multi): cross-attention query side — three data gradients, three weight gradients
+                dqc_, dqs_ = ops._c(dqc.reshape(T, D)), ops._c(dqs.reshape(T, D))
+                d_tgt1 = zTD()
+                gs_, ws_, ad_, dx_ = [dqc_], [Wcq], [ops._c(d_tgt1_res.reshape(T, D))], [d_tgt1]
+                d_sine_q = None
+                if (not first) or need_anchor:
+                    d_sine_q = zTD()
+                    gs_.append(dqs_); ws_.append(Wqs); ad_.append(None); dx_.append(d_sine_q)
+                if first:
+                    d_qpos = zTD()
+                    gs_.append(dqc_); ws_.append(Wcqp); ad_.append(None); dx_.append(d_qpos)
+                ops.linear_dgrad_multi(gs_, ws_, ad_, dx_, T, D, D)
+                (dWcq, dbcq), (dWqs, dbqs) = zW(), zW()
+                wg_ = [[dqc_, dqs_], [st["tgt1"], st["x_qs"]], [dWcq, dWqs], [dbcq, dbqs]]
+                if first:
+                    dWcqp, dbcqp = zW()
+                    wg_[0].append(dqc_); wg_[1].append(qpos); wg_[2].append(dWcqp); wg_[3].append(dbcqp)
+                _wgrad_multi(*wg_, T, D, D)
+            else:
+                d_sine_q, dWqs, dbqs, _ = _lin_b(dqs, st["x_qs"], Wqs, need_dx=(not first) or need_anchor)
+                if first:
+                    d_qpos, dWcqp, dbcqp, _ = _lin_b(dqc, qpos, Wcqp)
+                d_tgt1, dWcq, dbcq, _ = _lin_b(dqc, st["tgt1"], Wcq, add=d_tgt1_res)
             d_a, d_out_res, dWo, dbo, dg1, dbe1 = _outln_b(st["o1"], d_tgt1)
             r = ops.MhaSelfFn.backward(st["att"], d_a.view(1, T, D), None)
             dW_in = ops._zeros(like, 3 * D, D)
             dB_in = ops._zeros(like, 3 * D)
-            d_q, _, _, _ = _lin_b(r[0][0], q, W_in[:D], dw=dW_in[:D], db=dB_in[:D])
-            d_k, _, _, _ = _lin_b(r[1][0], k, W_in[D:2 * D], dw=dW_in[D:2 * D], db=dB_in[D:2 * D])
-            d_v, _, _, _ = _lin_b(r[2][0], v, W_in[2 * D:], dw=dW_in[2 * D:], db=dB_in[2 * D:])
-            nd = not first                              # layer 0's input state is the constant zero tensor
-            d_qpos, dWqp, dbqp, _ = _lin_b(d_q, qpos, Wqp, add=d_qpos)
-            _, dWqt, dbqt, _ = _lin_b(d_q, ctx.time_embed, Wqt, need_dx=False)
-            d_x, dWqc, dbqc, _ = _lin_b(d_q, x_out, Wqc, need_dx=nd, add=d_out_res.reshape(T, D) if nd else None)
-            d_qpos, dWkp, dbkp, _ = _lin_b(d_k, qpos, Wkp, add=d_qpos)
-            _, dWkt, dbkt, _ = _lin_b(d_k, ctx.time_embed, Wkt, need_dx=False)
-            d_x, dWkc, dbkc, _ = _lin_b(d_k, x_out, Wkc, need_dx=nd, add=d_x)
-            d_x, dWv, dbv, _ = _lin_b(d_v, x_out, Wv, need_dx=nd, add=d_x)
+            if mg:
+                # ... the three in-projections of nn.MultiheadAttention ...
+                gq, gk, gv = ops._c(r[0][0]), ops._c(r[1][0]), ops._c(r[2][0])
+                d_q, d_k, d_v = zTD(), zTD(), zTD()
+                ops.linear_dgrad_multi([gq, gk, gv], [W_in[:D], W_in[D:2 * D], W_in[2 * D:]], [None] * 3, [d_q, d_k, d_v], T, D, D)
+                _wgrad_multi([gq, gk, gv], [q, k, v], [dW_in[:D], dW_in[D:2 * D], dW_in[2 * D:]],
+                             [dB_in[:D], dB_in[D:2 * D], dB_in[2 * D:]], T, D, D)
+                # ... and the seven input projections: d_qpos = d_q Wqp + d_k Wkp (+ the cross-attention's share in layer 0),
+                # d_x = d_q Wqc + d_k Wkc + d_v Wv (+ the residual gradient)
+                te = ctx.time_embed
+                d_qpos_in = d_qpos
+                d_qpos = zTD()
+                gs_, ws_, ad_, dx_ = [d_q, d_k], [Wqp, Wkp], [d_qpos_in, None], [d_qpos, d_qpos]
+                d_x = None
+                if nd:
+                    d_x = zTD()
+                    gs_ += [d_q, d_k, d_v]; ws_ += [Wqc, Wkc, Wv]
+                    ad_ += [ops._c(d_out_res.reshape(T, D)), None, None]; dx_ += [d_x, d_x, d_x]
+                ops.linear_dgrad_multi(gs_, ws_, ad_, dx_, T, D, D)
+                (dWqp, dbqp), (dWqt, dbqt), (dWqc, dbqc), (dWkp, dbkp) = zW(), zW(), zW(), zW()
+                (dWkt, dbkt), (dWkc, dbkc), (dWv, dbv) = zW(), zW(), zW()
+                _wgrad_multi([d_q, d_q, d_q, d_k, d_k, d_k, d_v], [qpos, te, x_out, qpos, te, x_out, x_out],
+                             [dWqp, dWqt, dWqc, dWkp, dWkt, dWkc, dWv], [dbqp, dbqt, dbqc, dbkp, dbkt, dbkc, dbv], T, D, D)
+            else:
+                d_q, _, _, _ = _lin_b(r[0][0], q, W_in[:D], dw=dW_in[:D], db=dB_in[:D])
+                d_k, _, _, _ = _lin_b(r[1][0], k, W_in[D:2 * D], dw=dW_in[D:2 * D], db=dB_in[D:2 * D])
+                d_v, _, _, _ = _lin_b(r[2][0], v, W_in[2 * D:], dw=dW_in[2 * D:], db=dB_in[2 * D:])
+                d_qpos, dWqp, dbqp, _ = _lin_b(d_q, qpos, Wqp, add=d_qpos)
+                _, dWqt, dbqt, _ = _lin_b(d_q, ctx.time_embed, Wqt, need_dx=False)
+                d_x, dWqc, dbqc, _ = _lin_b(d_q, x_out, Wqc, need_dx=nd, add=d_out_res.reshape(T, D) if nd else None)
+                d_qpos, dWkp, dbkp, _ = _lin_b(d_k, qpos, Wkp, add=d_qpos)
+                _, dWkt, dbkt, _ = _lin_b(d_k, ctx.time_embed, Wkt, need_dx=False)
+                d_x, dWkc, dbkc, _ = _lin_b(d_k, x_out, Wkc, need_dx=nd, add=d_x)
+                d_x, dWv, dbv, _ = _lin_b(d_v, x_out, Wv, need_dx=nd, add=d_x)
             # ---- query_scale / ref_point_head / sine embedding
             if not first:
                 d_qsc = ops.ew2d(L.EW_MUL, d_sine_q, st["sine_h"])

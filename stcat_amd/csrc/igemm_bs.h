@@ -310,7 +310,7 @@ static __device__ __forceinline__ void stcat_bs_split_store(__bf16* dst, int pla
 // then carries twice the MFMA work per barrier while only 1.5x the operand bytes (tools/bench_quant.py: a second
 // co-resident 4-wave workgroup adds no throughput, so the CU is better spent on one bigger tile).
 template <int BM, int BN, int NS, int NWV = 4>
-__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p) {
+static __device__ __forceinline__ void igemm_bs_fwd_body(IgemmParams p) {
   STCAT_BS_PROLOGUE
   STCAT_BS_GATHER_DECL(BM)
   STCAT_BS_ACC_INIT
@@ -352,6 +352,32 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p
       }
     }
   }
+}
+
+template <int BM, int BN, int NS, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_fwd_kernel(IgemmParams p) {
+  igemm_bs_fwd_body<BM, BN, NS, NWV>(p);
+}
+
+// Several INDEPENDENT skinny problems of one shape in one launch (round 5): blockIdx.y picks the problem — the seven
+// input projections of a box-decoder layer's self-attention (query_decoder.py:329-338), its three in-projections, ...:
+// each was a ~8 us launch on a dependent chain although none depends on another.  Problems that write the SAME output
+// (q = Wqc tgt + Wqt time + Wqp pos) are separate problems of the accumulating split-K form (atomic epilogue onto a
+// zeroed output; slice 0 of each adds its bias).
+struct IgemmMulti {
+  IgemmParams base;
+  const float* A[8];
+  const float* B[8];
+  const float* bias[8];      // fwd: bias; dgrad: the `add` operand; wgrad: unused
+  float* C[8];
+  float* rowsum[8];          // wgrad: bias-gradient accumulators (may be null)
+};
+template <int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_fwd_multi_kernel(IgemmMulti mp) {
+  IgemmParams p = mp.base;
+  const int j = blockIdx.y;
+  p.A = mp.A[j]; p.B = mp.B[j]; p.bias = mp.bias[j]; p.C = mp.C[j];
+  igemm_bs_fwd_body<64, 64, NS, 4>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -456,7 +482,7 @@ __global__ void __launch_bounds__(256) igemm_bs_fwd_sk_fixup_kernel(IgemmParams 
 // dgrad: A = gathered dY (R), B[k=(tap,co)][n=ci] = W[co][tap][ci] (O)
 // ---------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS>
-__global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
+static __device__ __forceinline__ void igemm_bs_dgrad_body(IgemmParams p) {
   constexpr int NWV = 4;
   STCAT_BS_PROLOGUE
   constexpr int JB = (BN * 2 + 255) / 256;
@@ -524,11 +550,23 @@ __global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
   }
 }
 
+template <int BM, int BN, int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_kernel(IgemmParams p) {
+  igemm_bs_dgrad_body<BM, BN, NS>(p);
+}
+template <int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_dgrad_multi_kernel(IgemmMulti mp) {
+  IgemmParams p = mp.base;
+  const int j = blockIdx.y;
+  p.A = mp.A[j]; p.B = mp.B[j]; p.res = mp.bias[j]; p.C = mp.C[j];
+  igemm_bs_dgrad_body<64, 64, NS>(p);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wgrad: A[k=pixel][row=co] = dY (O), B[k=pixel][col=(tap,ci)] = gathered X (O); split-K over grid.z, atomics
 // ---------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS, int NWV = 4>
-__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
+static __device__ __forceinline__ void igemm_bs_wgrad_body(IgemmParams p) {
   STCAT_BS_PROLOGUE
   constexpr int JA = (BM * 2 + NTHR - 1) / NTHR, JB = (BN * 2 + NTHR - 1) / NTHR;
   const int tap = n0 / g.C, ci0 = n0 - tap * g.C;
@@ -636,4 +674,16 @@ __global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_wgrad_kernel(IgemmParams
       }
     }
   }
+}
+
+template <int BM, int BN, int NS, int NWV = 4>
+__global__ void __launch_bounds__(NWV * 64, 2) igemm_bs_wgrad_kernel(IgemmParams p) {
+  igemm_bs_wgrad_body<BM, BN, NS, NWV>(p);
+}
+template <int BM, int NS>
+__global__ void __launch_bounds__(256, 2) igemm_bs_wgrad_multi_kernel(IgemmMulti mp) {
+  IgemmParams p = mp.base;
+  const int j = blockIdx.y;
+  p.A = mp.A[j]; p.B = mp.B[j]; p.C = mp.C[j]; p.rowsum = mp.rowsum[j];
+  igemm_bs_wgrad_body<BM, BM, NS, 4>(p);
 }

@@ -938,6 +938,108 @@ int stcat_linear_dgrad_mask(const float* g, const float* w, const float* add, co
   return launch_dgrad(p, (hipStream_t)stream);
 }
 
+// ---- several independent skinny Linear problems of ONE shape in one launch (igemm_bs.h: IgemmMulti) ------------------
+// Accumulating forms (the outputs hold the value to add onto: zeros from the caller's arena), M <= 128, split-bf16 modes.
+// Problems may share an output (y = sum_j x_j w_j^T + b_j): the slices add atomically.
+static int multi_check(const char* what, int n, int M, int N, int K) {
+  if (n < 1 || n > 8) return fail("%s: 1 .. 8 problems (n=%d)", what, n);
+  if (M <= 0 || M > 128 || N % 64 != 0 || K % 64 != 0) return fail("%s: need M <= 128, N %% 64 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", what, M, N, K);
+  if (g_mma_mode == 0) return fail("%s: split-bf16 modes only", what);
+  return 0;
+}
+static int multi_splits(int nk, int tiles, int n) {   // reduction slices: >= 2 K-tiles each, at most ~512 workgroups in all
+  int splits = nk / 2;
+  if (splits > 8) splits = 8;
+  while (splits > 1 && (long)tiles * n * splits > 512) --splits;
+  return splits < 1 ? 1 : splits;
+}
+int stcat_linear_fwd_multi(int n, const float* x0, const float* x1, const float* x2, const float* x3, const float* x4, const float* x5, const float* x6, const float* x7, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5, const float* w6, const float* w7, const float* b0, const float* b1, const float* b2, const float* b3, const float* b4, const float* b5, const float* b6, const float* b7,
+                           float* y0, float* y1, float* y2, float* y3, float* y4, float* y5, float* y6, float* y7, int M, int N, int K, void* stream) {
+  if (int rc = multi_check("linear_fwd_multi", n, M, N, K)) return rc;
+  IgemmMulti mp = {};
+  const float* xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+  const float* ws[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+  const float* bs[8] = {b0, b1, b2, b3, b4, b5, b6, b7};
+  float* ys[8] = {y0, y1, y2, y3, y4, y5, y6, y7};
+  for (int j = 0; j < n; ++j) {
+    if (!xs[j] || !ws[j] || !ys[j] || !aligned16(xs[j]) || !aligned16(ws[j])) return fail("linear_fwd_multi: problem %d: null / unaligned operand", j);
+    mp.A[j] = xs[j]; mp.B[j] = ws[j]; mp.bias[j] = bs[j]; mp.C[j] = ys[j];
+  }
+  IgemmParams& p = mp.base;
+  p.a_bytes = bytes_of((long)M * K); p.b_bytes = bytes_of((long)N * K);
+  p.b_tap_stride = (unsigned)K * 4;
+  p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = N; p.ldr = 0; p.c_group = M; p.relu = 0;
+  p.g = conv_geom_fwd(1, 1, K, K, 1, 1, 1, 1, 1, 0);
+  const int tiles = cdiv(M, 64) * (N / 64), splits = multi_splits(K / 32, tiles, n);
+  p.k_chunk = cdiv(K / 32, splits);
+  const dim3 grid(tiles, n, cdiv(K / 32, p.k_chunk));
+  hipStream_t st = (hipStream_t)stream;
+  if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_fwd_multi_kernel<3>), grid, dim3(256), 0, st, mp); }
+  else { STCAT_LAUNCH((igemm_bs_fwd_multi_kernel<2>), grid, dim3(256), 0, st, mp); }
+  return launch_status();
+}
+
+// dx_j += g_j . w_j (+ add_j): the data gradients of such a group (outputs may coincide: d_x = sum_j g_j w_j)
+int stcat_linear_dgrad_multi(int n, const float* g0, const float* g1, const float* g2, const float* g3, const float* g4, const float* g5, const float* g6, const float* g7, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* w5, const float* w6, const float* w7, const float* a0, const float* a1, const float* a2, const float* a3, const float* a4, const float* a5, const float* a6, const float* a7,
+                             float* d0, float* d1, float* d2, float* d3, float* d4, float* d5, float* d6, float* d7, int M, int N, int K, void* stream) {
+  if (int rc = multi_check("linear_dgrad_multi", n, M, N, K)) return rc;
+  IgemmMulti mp = {};
+  const float* gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+  const float* ws[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+  const float* as[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+  float* ds[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+  for (int j = 0; j < n; ++j) {
+    if (!gs[j] || !ws[j] || !ds[j] || !aligned16(gs[j]) || !aligned16(ws[j])) return fail("linear_dgrad_multi: problem %d: null / unaligned operand", j);
+    mp.A[j] = gs[j]; mp.B[j] = ws[j]; mp.bias[j] = as[j]; mp.C[j] = ds[j];
+  }
+  IgemmParams& p = mp.base;          // as stcat_linear_dgrad: rows = M, columns = K (the Linear's inputs), reduction = N
+  p.a_bytes = bytes_of((long)M * N); p.b_bytes = bytes_of((long)N * K);
+  p.M = M; p.N = K; p.K = N; p.ldb = K; p.ldc = K; p.ldr = K; p.c_group = M; p.relu = 0;
+  IgemmGeom q;
+  q.H = 1; q.W = 1; q.C = N; q.ld = N; q.OH = 1; q.OW = 1; q.KH = 1; q.KW = 1;
+  q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
+  p.g = q;
+  const int tiles = cdiv(M, 64) * (K / 64), splits = multi_splits(N / 32, tiles, n);
+  p.k_chunk = cdiv(N / 32, splits);
+  const dim3 grid(tiles, n, cdiv(N / 32, p.k_chunk));
+  hipStream_t st = (hipStream_t)stream;
+  if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_dgrad_multi_kernel<3>), grid, dim3(256), 0, st, mp); }
+  else { STCAT_LAUNCH((igemm_bs_dgrad_multi_kernel<2>), grid, dim3(256), 0, st, mp); }
+  return launch_status();
+}
+
+// dw_j += g_j^T x_j, db_j += column sums of g_j: the weight gradients of such a group (N, K % 128 == 0)
+int stcat_linear_wgrad_multi(int n, const float* g0, const float* g1, const float* g2, const float* g3, const float* g4, const float* g5, const float* g6, const float* g7, const float* x0, const float* x1, const float* x2, const float* x3, const float* x4, const float* x5, const float* x6, const float* x7, float* dw0, float* dw1, float* dw2, float* dw3, float* dw4, float* dw5, float* dw6, float* dw7,
+                             float* db0, float* db1, float* db2, float* db3, float* db4, float* db5, float* db6, float* db7, int M, int N, int K, void* stream) {
+  if (n < 1 || n > 8) return fail("linear_wgrad_multi: 1 .. 8 problems (n=%d)", n);
+  if (M <= 0 || N % 128 != 0 || K % 128 != 0 || g_mma_mode == 0)
+    return fail("linear_wgrad_multi: need N, K %% 128 == 0 in a split-bf16 mode (M=%d N=%d K=%d)", M, N, K);
+  IgemmMulti mp = {};
+  const float* gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+  const float* xs[8] = {x0, x1, x2, x3, x4, x5, x6, x7};
+  float* dws[8] = {dw0, dw1, dw2, dw3, dw4, dw5, dw6, dw7};
+  float* dbs[8] = {db0, db1, db2, db3, db4, db5, db6, db7};
+  for (int j = 0; j < n; ++j) {
+    if (!gs[j] || !xs[j] || !dws[j] || !aligned16(gs[j]) || !aligned16(xs[j])) return fail("linear_wgrad_multi: problem %d: null / unaligned operand", j);
+    mp.A[j] = gs[j]; mp.B[j] = xs[j]; mp.C[j] = dws[j]; mp.rowsum[j] = dbs[j];
+  }
+  IgemmParams& p = mp.base;          // as stcat_linear_wgrad / launch_wgrad: rows = N, columns = K, reduction = M
+  p.ldb = N; p.ldc = K;
+  p.a_bytes = bytes_of((long)M * N); p.b_bytes = bytes_of((long)M * K);
+  p.g = conv_geom_fwd(1, 1, K, K, 1, 1, 1, 1, 1, 0);
+  p.M = N; p.N = K; p.K = M;
+  const int tiles = (N / 128) * (K / 128);
+  int nsplit = cdiv(M, 256);
+  if (nsplit < 1) nsplit = 1;
+  int chunk = ((cdiv(M, nsplit) + 31) / 32) * 32;
+  p.k_chunk = chunk;
+  const dim3 grid(tiles, n, cdiv(M, chunk));
+  hipStream_t st = (hipStream_t)stream;
+  if (g_mma_mode == 3) { STCAT_LAUNCH((igemm_bs_wgrad_multi_kernel<128, 3>), grid, dim3(256), 0, st, mp); }
+  else { STCAT_LAUNCH((igemm_bs_wgrad_multi_kernel<128, 2>), grid, dim3(256), 0, st, mp); }
+  return launch_status();
+}
+
 int stcat_colsum(const float* a, const float* b, float* out, int M, int N, void* stream);
 
 int stcat_linear_wgrad(const float* g, const float* x, float* dw, float* db, int M, int N, int K, int ldg, int ldx,
@@ -1532,6 +1634,9 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_linear_fwd_acc),
     STCAT_PLAN_FN(stcat_linear_dgrad_acc),
     STCAT_PLAN_FN(stcat_linear_fwd_drop),
+    STCAT_PLAN_FN(stcat_linear_fwd_multi),
+    STCAT_PLAN_FN(stcat_linear_dgrad_multi),
+    STCAT_PLAN_FN(stcat_linear_wgrad_multi),
     STCAT_PLAN_FN(stcat_linear_dgrad_mask),
     STCAT_PLAN_FN(stcat_linear_wgrad),
     STCAT_PLAN_FN(stcat_small_linear_fwd),

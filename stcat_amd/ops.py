@@ -321,6 +321,41 @@ def linear_fwd_raw(x2d, w, bias, res2d=None, relu=False, out=None, ldy=None, c_g
     return out
 
 
+def _pad8(xs):
+    xs = [L._ptr(x) for x in xs]
+    return xs + [None] * (8 - len(xs))
+
+
+def linear_multi_ok(M: int, N: int, K: int, like: torch.Tensor) -> bool:
+    """the grouped skinny-Linear launches apply: a split-bf16 mode, M <= 128, 64-multiples, and a source of zeroed outputs"""
+    return (MULTI_LINEAR and L.get_mma_mode() != "f32" and M <= 128 and N % 64 == 0 and K % 64 == 0
+            and (L.RECORDER is not None or _ARENA.get(str(like.device)) is not None))
+
+
+def linear_fwd_multi(xs, ws, bs, ys, M, N, K):
+    """ys[j] += xs[j] ws[j]^T + bs[j] for up to 8 problems of one shape in ONE launch (ys zeroed by the caller, may coincide)"""
+    n = len(xs)
+    assert 1 <= n <= 8 and len(ws) == n and len(bs) == n and len(ys) == n
+    L.call("stcat_linear_fwd_multi", n, *_pad8(xs), *_pad8(ws), *_pad8(bs), *_pad8(ys), M, N, K, L.stream_of(xs[0]))
+
+
+def linear_dgrad_multi(gs, ws, adds, dxs, M, N, K):
+    """dxs[j] += gs[j] ws[j] (+ adds[j]); ws[j] is [N, K]"""
+    n = len(gs)
+    assert 1 <= n <= 8
+    L.call("stcat_linear_dgrad_multi", n, *_pad8(gs), *_pad8(ws), *_pad8(adds), *_pad8(dxs), M, N, K, L.stream_of(gs[0]))
+
+
+def linear_wgrad_multi(gs, xs, dws, dbs, M, N, K):
+    """dws[j] += gs[j]^T xs[j], dbs[j] += column sums of gs[j]"""
+    n = len(gs)
+    assert 1 <= n <= 8
+    L.call("stcat_linear_wgrad_multi", n, *_pad8(gs), *_pad8(xs), *_pad8(dws), *_pad8(dbs), M, N, K, L.stream_of(gs[0]))
+
+
+MULTI_LINEAR = not os.environ.get("STCAT_NO_MULTI_LINEAR")
+
+
 def act_bwd_raw(dy, y, scale, want_g=True, want_res=False, relu=True):
     dy = _c(dy)
     n = dy.numel()

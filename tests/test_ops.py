@@ -348,6 +348,48 @@ def _pl_dgrad_coarse_add(dev, big):
 
 
 @both
+def _linear_multi(dev, big):
+    """stcat_linear_{fwd,dgrad,wgrad}_multi: several skinny problems of one shape in one launch, outputs shared between
+    problems (q = sum of three projections), against fp64"""
+    old_mode = L.get_mma_mode()
+    try:
+        for mode in (("f32",) if dev.type == "cpu" else ()) + ("bf16x6", "bf16x3"):
+            if mode == "f32":
+                continue
+            L.set_mma_mode(mode)
+            tol = 2e-5 if mode == "bf16x6" else 3e-4
+            for (M, N, K, n) in ((64, 256, 256, 7), (65, 128, 256, 3), (33, 256, 128, 2)):
+                xs = [rnd(M, K, seed=10 + j).to(dev) for j in range(n)]
+                ws = [rnd(N, K, seed=30 + j, scale=K ** -0.5).to(dev) for j in range(n)]
+                bs = [rnd(N, seed=50 + j).to(dev) for j in range(n)]
+                # outputs: problems 0..2 share y0 when n >= 3
+                share = [0 if (n >= 3 and j < 3) else j for j in range(n)]
+                ys = {k: torch.zeros(M, N, device=dev) for k in set(share)}
+                ops.linear_fwd_multi(xs, ws, bs, [ys[share[j]] for j in range(n)], M, N, K)
+                for k in ys:
+                    want = sum(xs[j].cpu().double() @ ws[j].cpu().double().t() + bs[j].cpu().double() for j in range(n) if share[j] == k)
+                    close(ys[k], want.float(), tol, f"linear_fwd_multi [{mode}] M{M} N{N} K{K} out{k}")
+                gs = [rnd(M, N, seed=70 + j).to(dev) for j in range(n)]
+                adds = [rnd(M, K, seed=90 + j).to(dev) if j % 2 == 0 else None for j in range(n)]
+                dxs = {k: torch.zeros(M, K, device=dev) for k in set(share)}
+                ops.linear_dgrad_multi(gs, ws, adds, [dxs[share[j]] for j in range(n)], M, N, K)
+                for k in dxs:
+                    want = sum(gs[j].cpu().double() @ ws[j].cpu().double() + (adds[j].cpu().double() if adds[j] is not None else 0)
+                               for j in range(n) if share[j] == k)
+                    close(dxs[k], want.float(), tol, f"linear_dgrad_multi [{mode}] out{k}")
+                if N % 128 == 0 and K % 128 == 0:
+                    dws = [torch.zeros(N, K, device=dev) for _ in range(n)]
+                    dbs = [torch.zeros(N, device=dev) if j != 1 else None for j in range(n)]
+                    ops.linear_wgrad_multi(gs, xs, dws, dbs, M, N, K)
+                    for j in range(n):
+                        close(dws[j], (gs[j].cpu().double().t() @ xs[j].cpu().double()).float(), tol, f"linear_wgrad_multi [{mode}] dw{j}")
+                        if dbs[j] is not None:
+                            close(dbs[j], gs[j].cpu().double().sum(0).float(), tol, f"linear_wgrad_multi [{mode}] db{j}")
+    finally:
+        L.set_mma_mode(old_mode)
+
+
+@both
 def _pl_maxpool(dev, big):
     n, H, C = (2, 10, 64) if not big else (4, 112, 64)
     x = rnd(n, C, H, H, seed=1)
