@@ -82,7 +82,15 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
                 add = add if add.is_contiguous() else add.contiguous()
             dx = (ops._zero_take(g, (M, K)) if (M <= 128 and N >= 128 and L.get_mma_mode() != "f32" and mask is None)
                   else None)
-            if mask is not None:
+            if mask is not None and mask[0] == "bits":
+                # the Linear's input was dropout(relu(.)) written by the plane kernel with its bit mask: data gradient on the
+                # A-stationary plane kernel (K_red = N = 256 -> 2048 columns), ReLU + dropout backward from the bits
+                _, ybits, gainvec, wtp = mask
+                gp = ops.pl_split(g)
+                dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+                L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, wtp.h, wtp.l, ybits.data_ptr(), gainvec.data_ptr(),
+                       dx.data_ptr(), M, N, K, st)
+            elif mask is not None:
                 my, gain = mask
                 dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
                 wt = ops.LINEAR_WT.get(w) if M > 256 else None
@@ -262,7 +270,38 @@ def _outln_b(st, dy, need_da=True, mask=None):
 FUSE_FFN = not os.environ.get("STCAT_NO_FFN_FUSE")
 
 
-def _ffn_f(x, W1, b1, W2, b2, g, be, p):
+FFN_PLANES = not os.environ.get("STCAT_NO_FFN_PLANES")
+
+
+class FfnPlanes:
+    """per-encoder cache for the FFN's wide side on the plane kernels (round 5): weight planes of linear1 (forward form)
+    and linear2 (transposed form) of the layers whose token matrix is big enough, refreshed by ONE launch per forward pass,
+    plus the constant 1 / (1 - p) vectors of the masked data gradient"""
+
+    def __init__(self):
+        self.wp = ops.WeightPlanes()
+        self.gain = {}
+
+    def refresh(self, pairs, need_bwd: bool):
+        """pairs: [(W1 [F, D], W2 [D, F]), ...] -> {id(W1): (planes of W1, transposed planes of W2)}"""
+        ws = []
+        for W1, W2 in pairs:
+            ws.append(W1.view(W1.shape[0], 1, 1, W1.shape[1]))
+            ws.append(W2.view(W2.shape[0], 1, 1, W2.shape[1]))
+        fwd, tr = self.wp.refresh(ws, transposed=need_bwd)
+        return {W1.data_ptr(): (fwd[W1.data_ptr()], tr.get(W2.data_ptr()) if need_bwd else None) for W1, W2 in pairs}
+
+    def gainvec(self, like, n: int, gain: float):
+        key = (str(like.device), n, round(gain, 9))
+        v = self.gain.get(key)
+        if v is None:
+            if L.RECORDER is not None:
+                return None            # (cannot be created inside a recording: the eager first call makes it)
+            v = self.gain[key] = torch.full((n,), gain, device=like.device, dtype=torch.float32)
+        return v
+
+
+def _ffn_f(x, W1, b1, W2, b2, g, be, p, pl=None):
     """norm(x + dropout(linear2(dropout(relu(linear1 x)))))  (modal_encoder.py:239-241; query_decoder.py:435-437, 657-659).
     Round 5: the ReLU AND the inner dropout ride in linear1's epilogue (stcat_linear_fwd_drop), their backward in the
     epilogue of linear2's data gradient (stcat_linear_dgrad_mask): per layer one [M, 2048] pass less forward (the dropout
@@ -275,6 +314,19 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p):
         if not (x2.is_contiguous() or (x2.stride(1) == 1 and x2.stride(0) % 4 == 0)):
             x2 = x2.contiguous()
         M, N = x2.shape[0], W1.shape[0]
+        ent = pl[0].get(W1.data_ptr()) if pl is not None else None
+        gv = pl[1].gainvec(x, N, 1.0 / (1.0 - p) if p > 0.0 else 1.0) if ent is not None else None
+        if ent is not None and gv is not None and x2.is_contiguous():
+            # linear1 on the A-stationary plane kernel (K = 256 -> N = 2048: its shape), operands as planes
+            w1p, w2t = ent
+            xp = ops.pl_split(x2)
+            f1d = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            ymask = torch.empty(M, N // 8, device=x.device, dtype=torch.uint8)
+            seed, off, base = ops._dropout_stream.take(M * N, x.device) if p > 0.0 else (0, 0, None)
+            L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, L._ptr(b1), f1d.data_ptr(), ymask.data_ptr(), M, N, K, 1,
+                   float(p), seed, off, base, L.stream_of(x2))
+            y, st = _outln_f(f1d.view(*shp[:-1], N), W2, b2, x, g, be, p)
+            return y, (st, ("bits", ymask, gv, w2t), x2, f1d, W1)
         if p > 0.0:
             seed, off, base = ops._dropout_stream.take(M * N, x.device)
             f1d = torch.empty(M, N, device=x.device, dtype=torch.float32)
@@ -296,6 +348,10 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p):
 def _ffn_b(st, dy):
     """-> (d_x [M,D], dW1, db1, dW2, db2, dg, dbe)"""
     st_o, c_dr, x_1, f1, W1 = st
+    if isinstance(c_dr, tuple) and c_dr[0] == "bits":
+        d_f1, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy, mask=c_dr)
+        d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, add=d_x_res)
+        return d_x, dW1, db1, dW2, db2, dg, dbe
     if isinstance(c_dr, tuple) and c_dr[0] == "fused":
         d_f1, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy, mask=(f1, c_dr[1]))     # f1 = dropout(relu(.)) here
         d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, add=d_x_res)
@@ -332,7 +388,7 @@ def _ln_b(st, dy, dg, dbe):
 # ------------------------------------------------------------------------------------------------------------------
 class EncoderLayerFn(Function):
     @staticmethod
-    def forward(ctx, x, pos, kpm, p, nhead, W_in, B_in, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
+    def forward(ctx, x, pos, kpm, p, nhead, W_in, B_in, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, ffn_pl=None):
         D = x.shape[-1]
         shp = x.shape
         x = x if x.is_contiguous() else x.contiguous()
@@ -343,7 +399,7 @@ class EncoderLayerFn(Function):
         (a, _), c_att = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk, qk[:, :, D:], v, kpm,
                            (D // nhead) ** -0.5, False, True, p)
         x1, st1 = _outln_f(a, Wo, bo, x, g1, be1, p)
-        y, st2 = _ffn_f(x1, W1, b1, W2, b2, g2, be2, p)
+        y, st2 = _ffn_f(x1, W1, b1, W2, b2, g2, be2, p, pl=ffn_pl)
         ctx.st = (c_att, st1, st2, x_qk, x_v, D, shp, pos.shape)
         ctx.W_in = W_in
         return y
@@ -861,7 +917,7 @@ class EncoderFn(Function):
     (as the reference's `src[0] = ...` does) and the backward routes those slots' gradients the same way."""
 
     @staticmethod
-    def forward(ctx, vis_tokens, txt, vis_pos, kpm, tpos, p, nhead, nl, frame_cls, local_pos, video_cls, *prm):
+    def forward(ctx, vis_tokens, txt, vis_pos, kpm, tpos, p, nhead, nl, wpc, frame_cls, local_pos, video_cls, *prm):
         n, HW, d = vis_tokens.shape
         Lt = txt.shape[0]
         S1 = 1 + HW + Lt
@@ -877,11 +933,18 @@ class EncoderFn(Function):
         ops.ew2d(L.EW_COPY, vis_pos.view(n, HW * d), out=_cols(pos, 1, 1 + HW))
         video = video_cls.view(1, d)
         ctxs = []
+        ffn_pl = None
+        if (wpc is not None and FFN_PLANES and FUSE_FFN and L.get_mma_mode() == "bf16x6p" and n * S1 >= 4096 and d == 256
+                and vis_tokens.is_cuda):
+            # the spatial layers' FFN (13 248 x 256 -> 2048 at C3) on the plane kernels: ONE refresh of their weight planes
+            pairs = [(prm[(2 * i) * _NE_LAYER + 6], prm[(2 * i) * _NE_LAYER + 8]) for i in range(nl)]
+            need_bwd = any(w.requires_grad for pr in pairs for w in pr)
+            ffn_pl = (wpc.refresh(pairs, need_bwd), wpc)
         for i in range(nl):
             sp = prm[(2 * i) * _NE_LAYER:(2 * i + 1) * _NE_LAYER]
             tp = prm[(2 * i + 1) * _NE_LAYER:(2 * i + 2) * _NE_LAYER]
             c_s = _Ctx((True, True))
-            x1 = EncoderLayerFn.forward(c_s, x, pos, kpm, p, nhead, *sp)                       # :163-168
+            x1 = EncoderLayerFn.forward(c_s, x, pos, kpm, p, nhead, *sp, ffn_pl=ffn_pl)        # :163-168
             seq = ops._empty(x, 1, n + 1, d)                                                   # :170-177
             ops.ew(L.EW_COPY, video, out=seq[0, 0:1])
             ops.ew2d(L.EW_COPY, _cols(x1, 0, 1), out=seq[0, 1:])
@@ -943,7 +1006,7 @@ class EncoderFn(Function):
         for g in grads:
             flat += tuple(g)
         ops.dropout_backward_done()   # (a frozen backbone has no backward node: this is then the path's last one)
-        return (d_vis, d_txt, None, None, None, None, None, None, d_fc, ops.colsum(d_lp).view(1, d),
+        return (d_vis, d_txt, None, None, None, None, None, None, None, d_fc, ops.colsum(d_lp).view(1, d),
                 ops.ew(L.EW_COPY, d_video)) + flat
 
 
@@ -956,8 +1019,11 @@ def encoder(enc, vis_tokens, txt, vis_pos, kpm_full, tpos):
             sa = l.self_attn
             prm += (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, l.norm1.weight, l.norm1.bias,
                     l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias)
+    wpc = enc.__dict__.get("_ffn_planes")
+    if wpc is None:
+        wpc = enc.__dict__["_ffn_planes"] = FfnPlanes()
     return plans.apply(EncoderFn, vis_tokens, txt, vis_pos, kpm_full, tpos, p, enc.spatial_layers[0].nhead, enc.num_layers,
-                           enc.frame_cls.weight, enc.local_pos_embed.weight, enc.video_cls.weight, *prm)
+                           wpc, enc.frame_cls.weight, enc.local_pos_embed.weight, enc.video_cls.weight, *prm)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -63,6 +63,9 @@ struct PlParams {
                                         // (0 = off); set by the launcher for many-round, epilogue-heavy launches
   int debug;                            // timing experiments only (stcat_debug_pl_flags): 1 = no wgrad atomics,
                                         // 2 = epilogue without global loads / stores
+  DropParams drop;                      // fwd kernels, round 5: dropout on the epilogue's result (after ReLU), element index
+                                        // m * N + n of the site's counter range — a Linear on planes with the FFN's
+                                        // `dropout(relu(.))` in its epilogue (dense [M, N] output)
   int radd_div, radd_h, radd_w;         // fwd kernel, round 5: the residual / `add` planes live on the COARSE grid of a stride-
                                         // radd_div conv ([n][radd_h][radd_w][ldr]) and are added at the output pixels on its
                                         // lattice only ((oh, ow) multiples of radd_div; nothing elsewhere): the data gradient
@@ -507,6 +510,12 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
         if (p.relu) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+        }
+        if (p.drop.thresh) {
+          const DropParams dp_ = stcat_drop_resolve(p.drop);
+          const unsigned long long i0_ = (unsigned long long)m * (unsigned long long)p.N + (unsigned long long)n;
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] *= stcat_drop_mul(dp_, i0_ + e);
         }
         if (p.Mi) {
           const unsigned bits = cur.bits[ps];

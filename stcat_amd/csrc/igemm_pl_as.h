@@ -241,6 +241,12 @@ __global__ void __launch_bounds__(256, 2) igemm_pl_as_kernel(PlParams p) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
         }
+        if (p.drop.thresh) {
+          const DropParams dp_ = stcat_drop_resolve(p.drop);
+          const unsigned long long i0_ = (unsigned long long)em * (unsigned long long)p.N + (unsigned long long)n;
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) x[e] *= stcat_drop_mul(dp_, i0_ + e);
+        }
         if (p.Mi) {
           const unsigned bits = pre.bits[ps];
           STCAT_UNROLL

@@ -1448,6 +1448,50 @@ int stcat_pl_conv_dgrad_cadd(const void* gh, const void* gl, const void* th, con
   return launch_pl_fwd(p, (hipStream_t)stream);
 }
 
+// ---- Linear layers on the plane kernels (round 5): the encoder FFN's wide side (modal_encoder.py:239-240, K = 256 ->
+// N = 2048 at 13 248 rows) is exactly the A-stationary kernel's shape; operands arrive as planes (stcat_pl_split of the
+// LayerNorm output / the upstream gradient: 10 us), results leave as fp32 for the consumers that stay on fp32 tensors.
+// y = dropout_p(relu?(x w^T + bias)) [M, N] fp32 (+ the bit mask y > 0 for the backward pass)
+int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* bias, float* yf,
+                        unsigned char* ymask, int M, int N, int K, int relu, float drop_p, long drop_seed, long drop_offset,
+                        const long* drop_base, void* stream) {
+  if (K % 32 != 0 || N % 64 != 0 || M <= 0) return fail("pl_linear_fwd: need K %% 32 == 0, N %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+  if (!aligned16(xh) || !aligned16(xl) || !aligned16(wh) || !aligned16(wl) || !yf) return fail("pl_linear_fwd: planes must be 16-byte aligned, yf set");
+  if (g_mma_mode_raw < 4) return fail("pl_linear_fwd: plane modes only");
+  PlParams p = {};
+  p.Ah = (const __bf16*)xh; p.Al = (const __bf16*)xl; p.Bh = (const __bf16*)wh; p.Bl = (const __bf16*)wl;
+  p.Cf = yf; p.Mo = ymask; p.bias = bias; p.relu = relu;
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
+  p.a_bytes = plane_bytes((long)M * K); p.b_bytes = plane_bytes((long)N * K);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_linear_fwd: a plane exceeds 2 GB");
+  p.b_tap_stride = (unsigned)K;
+  p.M = M; p.N = N; p.K = K; p.ldb = K; p.ldc = N; p.ldr = N;
+  p.g = conv_geom_fwd(1, M, K, K, 1, M, 1, 1, 1, 0);
+  return launch_pl_fwd(p, (hipStream_t)stream);
+}
+
+// dx [M, K] fp32 = [ybits] mask_scale[k] * (g [M, N] . w [N, K]); th / tl = the TRANSPOSED weight planes [K][N]
+int stcat_pl_linear_dgrad_mask(const void* gh, const void* gl, const void* th, const void* tl, const unsigned char* ybits,
+                               const float* mask_scale, float* dxf, int M, int N, int K, void* stream) {
+  if (N % 32 != 0 || K % 64 != 0 || M <= 0) return fail("pl_linear_dgrad_mask: need N %% 32 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+  if (!aligned16(gh) || !aligned16(gl) || !aligned16(th) || !aligned16(tl) || !dxf) return fail("pl_linear_dgrad_mask: planes must be 16-byte aligned, dxf set");
+  if (g_mma_mode_raw < 4) return fail("pl_linear_dgrad_mask: plane modes only");
+  PlParams p = {};
+  p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)th; p.Bl = (const __bf16*)tl;
+  p.Cf = dxf; p.Mi = ybits; p.mscale = mask_scale;
+  p.a_bytes = plane_bytes((long)M * N); p.b_bytes = plane_bytes((long)N * K);
+  if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_linear_dgrad_mask: a plane exceeds 2 GB");
+  p.ldb = N; p.b_tap_stride = (unsigned)((long)K * N);
+  p.M = M; p.N = K; p.K = N; p.ldc = K; p.ldr = K; p.relu = 0;
+  IgemmGeom q;
+  q.H = 1; q.W = M; q.C = N; q.ld = N; q.OH = 1; q.OW = M; q.KH = 1; q.KW = 1;
+  q.mul = 1; q.off = 0; q.sgn = -1; q.div = 1;
+  stcat_fastdiv_magic(M, &q.mg_ow, &q.sh_ow);
+  stcat_fastdiv_magic(M, &q.mg_ohw, &q.sh_ohw);
+  p.g = q;
+  return launch_pl_fwd(p, (hipStream_t)stream);
+}
+
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
                         int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
@@ -1669,6 +1713,8 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_pl_conv_fwd),
     STCAT_PLAN_FN(stcat_pl_conv_dgrad),
     STCAT_PLAN_FN(stcat_pl_conv_dgrad_cadd),
+    STCAT_PLAN_FN(stcat_pl_linear_fwd),
+    STCAT_PLAN_FN(stcat_pl_linear_dgrad_mask),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad),
     STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),
     STCAT_PLAN_FN(stcat_pl_split),

@@ -390,6 +390,52 @@ def _linear_multi(dev, big):
 
 
 @both
+def _pl_linear_ffn(dev, big):
+    """stcat_pl_linear_fwd / stcat_pl_linear_dgrad_mask (the encoder FFN's wide side on the plane kernels): y = dropout(relu(
+    x W1^T + b)) with the kernels' own counter-based mask (== stcat_dropout on the dense tensor), its bit mask, and
+    dx = [bits] gain (g W2) — against fp64"""
+    old_mode = L.get_mma_mode()
+    L.set_mma_mode("bf16x6p")
+    try:
+        for (M, K, N, p) in ((70, 256, 512, 0.25), (130, 128, 256, 0.0)) + (((13248, 256, 2048, 0.1),) if big else ()):
+            x = rnd(M, K, seed=1).to(dev)
+            w1 = rnd(N, K, seed=2, scale=K ** -0.5).to(dev)
+            b1 = rnd(N, seed=3).to(dev)
+            w2 = rnd(K, N, seed=4, scale=N ** -0.5).to(dev)             # linear2: [D, F]
+            fwd, tr = ops.WeightPlanes().refresh([w1.view(N, 1, 1, K), w2.view(K, 1, 1, N)], transposed=True)
+            w1p, w2t = fwd[w1.data_ptr()], tr[w2.data_ptr()]
+            xp = ops.pl_split(x)
+            y = torch.empty(M, N, device=dev)
+            bits = torch.empty(M, N // 8, device=dev, dtype=torch.uint8)
+            ops.manual_seed(5)
+            seed, off, base = ops._dropout_stream.take(M * N, x.device) if p > 0 else (0, 0, None)
+            L.call("stcat_debug_force_pl_tile", 7 if not big else -1)
+            try:
+                L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, b1.data_ptr(), y.data_ptr(), bits.data_ptr(), M, N, K, 1,
+                       float(p), seed, off, base, L.stream_of(x))
+                ref = torch.relu(x.cpu().double() @ w1.cpu().double().t() + b1.cpu().double())
+                if p > 0:
+                    keep = torch.from_numpy(ops.dropout_keep_mask(seed, off + int(ops._dropout_stream.base(x.device).item()), M * N, p))
+                    ref = ref * keep.view(M, N) / (1.0 - p)
+                close(y, ref.float(), 2e-5, f"pl_linear_fwd M{M} K{K} N{N} p{p}")
+                want_bits = ((y.reshape(M, N // 8, 8) > 0).to(torch.int32) << torch.arange(8, device=y.device).to(torch.int32)).sum(-1)
+                assert torch.equal(bits.to(torch.int32), want_bits), "pl_linear_fwd bit mask"
+                g = rnd(M, K, seed=6).to(dev)                              # gradient at linear2's output [M, D]
+                gp = ops.pl_split(g)
+                gain = 1.0 / (1.0 - p)
+                gv = torch.full((N,), gain, device=dev)
+                dx = torch.empty(M, N, device=dev)
+                L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, w2t.h, w2t.l, bits.data_ptr(), gv.data_ptr(), dx.data_ptr(), M, K, N,
+                       L.stream_of(x))
+            finally:
+                L.call("stcat_debug_force_pl_tile", -1)
+            refd = (g.cpu().double() @ w2.cpu().double()) * (y.cpu() > 0) * gain
+            close(dx, refd.float(), 2e-5, f"pl_linear_dgrad_mask M{M}")
+    finally:
+        L.set_mma_mode(old_mode)
+
+
+@both
 def _pl_maxpool(dev, big):
     n, H, C = (2, 10, 64) if not big else (4, 112, 64)
     x = rnd(n, C, H, H, seed=1)
