@@ -59,6 +59,12 @@ def clear() -> None:
     for cache in _CACHES:
         cache.clear()
     invalidate()
+    # the dropped entries own torch.cuda.MemPool objects and sit in reference cycles (ctx <-> tensors): collect them NOW.
+    # Left to the cyclic GC, a pool's destructor may run in the middle of a later recording — inside
+    # torch.cuda.use_mem_pool — where the caching allocator aborts the process (captures_underway.empty() assert; seen in
+    # round 5 with bench.py's mode loop under a live RCCL group)
+    import gc
+    gc.collect()
 
 
 _CACHES: List[list] = []
@@ -432,6 +438,9 @@ def _record(dev, ext, pool, body):
     watch = _Watch(rec, keepalive=(not cuda) or KEEPALL)
     prev = L.RECORDER
     L.RECORDER = rec
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()          # (no destructor of an old plan's memory pool inside use_mem_pool: see clear())
     try:
         if cuda:
             with torch.cuda.use_mem_pool(pool, device=dev):
@@ -445,6 +454,8 @@ def _record(dev, ext, pool, body):
                 res = body()
     finally:
         L.RECORDER = prev
+        if gc_was_on:
+            gc.enable()
     plan = rec.finalize()
     if rec.foreign:
         if STRICT:
