@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   unsigned a_c16[RQA], b_voff[RQB];
   STCAT_UNROLL
   for (int i = 0; i < RQA; ++i) {
-    const int q = wave + NW * i, r = q * 16 + (lane >> 2), m = m0 + r;
+    const int q = wave + NW * i, r = q * 16 + (lane >> 2), m = ((p.debug & 256) ? 0 : m0) + r;   // (debug 256: every tile loads rows 0..BM-1 — L2 hits)
     a_c16[i] = (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 16);
     a_nb[i] = -1; a_bh[i] = 0; a_bw[i] = 0;
     if (q < QA && m < Mc) {
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   const int dmask = g.div - 1, dshift = g.div > 1 ? 31 - __builtin_clz(g.div) : 0;  // div is 1 or a power of two
 #define STCAT_PL_STAGE_LOAD(ST)                                                                         \
   {                                                                                                     \
-    const bool live_ = kl < nk;                                                                         \
+    const bool live_ = (kl < nk) & !(p.debug & 512);   /* (debug 512: zero-fill DMA, no operand traffic) */ \
     stcat_buf_t dA_[NPL], dB_[NPL];                                                                     \
     STCAT_UNROLL                                                                                        \
     for (int pi_ = 0; pi_ < NPL; ++pi_) {                                                               \
@@ -358,8 +358,9 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
   STCAT_UNROLL
   for (int ks = 0; ks < 2; ++ks) {
     const int c = ks * 2 + hi, sw = (l31 >> 2) & 3;
-    fa_off[ks] = (unsigned)((wm * TM * 32 + l31) * 64 + ((c ^ sw) * 16));
-    fb_off[ks] = (unsigned)(NP * PLANE_A + (wn * TN * 32 + l31) * 64 + ((c ^ sw) * 16));
+    const int lr = (p.debug & 1) ? 0 : l31;     // (debug 1: every lane reads row 0 — LDS broadcast, timing experiment)
+    fa_off[ks] = (unsigned)((wm * TM * 32 + lr) * 64 + ((c ^ sw) * 16));
+    fb_off[ks] = (unsigned)(NP * PLANE_A + (wn * TN * 32 + lr) * 64 + ((c ^ sw) * 16));
   }
   struct Frag { bf16x8 a[NPL][TM], b[NPL][TN]; };
 #define STCAT_PL_READ_FRAG(F, SB, KS)                                                                   \

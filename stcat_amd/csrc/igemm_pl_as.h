@@ -58,6 +58,16 @@ __global__ void __launch_bounds__(256, 2) igemm_pl_as_kernel(PlParams p) {
   }
   const int m0 = rb * BM, nu0 = c_first * BN;
   float* ew = reinterpret_cast<float*>(smem + KS * SLOT + wave * EPI_WAVE);
+#ifndef STCAT_EMU
+  if (p.stagger > 0 && blockIdx.x < 2u * 256u && (blockIdx.x & 256u)) {
+    // Phase offset between the two workgroups that share a CU (experiment): every workgroup of a launch costs the same, so
+    // the two start together and stay in step — K loops together (one matrix pipe), epilogues together (one memory
+    // path).  The second-slot workgroups of the first round wait half a chunk-pair period once.
+    const long t0 = (long)wall_clock64();
+    long tt = t0;
+    while (tt - t0 < (long)p.stagger) { __builtin_amdgcn_s_sleep(8); tt = (long)wall_clock64(); }
+  }
+#endif
 
   // ---- the wave's 16 activation rows as MFMA A fragments: lane (l15, kg) holds row l15, terms 32 s + 8 kg .. + 7
   bf16x8 Ar[NP][KS];
@@ -91,7 +101,7 @@ __global__ void __launch_bounds__(256, 2) igemm_pl_as_kernel(PlParams p) {
   }
 #define STCAT_AS_ISSUE(CC, SP)                                                                          \
   {                                                                                                     \
-    const bool live_ = (CC) < cpu;                                                                      \
+    const bool live_ = ((CC) < cpu) & !(p.debug & 256);   /* (debug 256: zero-fill weight DMA, timing experiment) */ \
     STCAT_UNROLL                                                                                        \
     for (int i_ = 0; i_ < 3; ++i_) {                                                                    \
       const __bf16* bp_ = pc_plane[i_] == 0 ? Bp[0] : (pc_plane[i_] == 1 ? Bp[1] : Bp[2]);              \

@@ -411,6 +411,7 @@ int pick_pl_tile(int M, int N, int K) {
 }
 
 // ---- A-stationary form (igemm_pl_as.h): 1x1, stride 1, K = 64 / 128 / 256, three bf16 planes ---------------------
+int g_pl_as_skew = 0;    // stcat_debug_pl_flags bit 0x2000: flags >> 16 = the A-stationary kernel's phase offset in 10 ns ticks
 bool pl_as_ok(const PlParams& p) {
   if (!g_pl_as || g_pl_np != 3 || g_pl_f16) return false;
   if (g_pl_force >= 0 && g_pl_force != 7) return false;            // a test / experiment asked for a tile of the table
@@ -438,8 +439,10 @@ static int wg_slots_as() {   // workgroup slots of the chip for the A-stationary
 }
 template <int KS>
 int launch_pl_as_ks(PlParams& p, hipStream_t st) {
-  constexpr int lds = KS * 3 * 32 * 64 + 4 * 16 * 68 * 4;
-  if (int rc = pl_prepare(igemm_pl_as_kernel<KS>, lds)) return rc;
+  constexpr int lds_min = KS * 3 * 32 * 64 + 4 * 16 * 68 * 4;
+  // (experiment 0x1000: ONE workgroup per CU — the LDS request is raised past half the CU's 160 KB)
+  const int lds = ((g_pl_debug & 0x1000) && !(g_pl_debug & 8)) ? 96 * 1024 : lds_min;
+  if (int rc = pl_prepare(igemm_pl_as_kernel<KS>, 96 * 1024)) return rc;
   // resident workgroups per CU: 2 at K = 256 (196 VGPRs), 3 at K = 128 (148), 4 at K = 64 (124)
   const int rbs = cdiv(p.M, 64), chunks = p.N / 32, slots = wg_slots_as() / 2 * (KS == 8 ? 2 : (KS == 4 ? 3 : 4));
   // whole rounds of the chip as whole row blocks (activation rows read once); the partial last round in quarter runs
@@ -453,6 +456,7 @@ int launch_pl_as_ks(PlParams& p, hipStream_t st) {
   if (rbs - tier1 == 0) cpu = chunks;
   p.par = tier1;
   p.k_chunk = cpu;
+  p.stagger = g_pl_as_skew;      // 10 ns ticks; second-slot workgroups of the first round (igemm_pl_as.h)
   const int grid = tier1 + (rbs - tier1) * (chunks / cpu);
   STCAT_LAUNCH((igemm_pl_as_kernel<KS>), dim3(grid), dim3(256), lds, st, p);
   return launch_status();
@@ -1365,6 +1369,8 @@ int stcat_debug_force_pl_tile(int index) {
 }
 
 int stcat_debug_pl_flags(int flags) {
+  g_pl_as_skew = (flags & 0x2000) ? ((flags >> 16) & 0xffff) : 0;
+  if (flags & 0x2000) flags &= 0x1fff;
   g_pl_debug = flags & ~(4 | 128);     // bits 0,1,3.. : timing experiments (PlParams::debug, stagger)
   g_pl3_small = (flags & 4) ? 1 : 0;   // bit 2: three-plane short reductions on the two-workgroup 128 x 64 tile
   g_pl_as = (flags & 128) ? 0 : 1;     // bit 7: the K <= 256 1x1 layers back on the two-stage tile kernel (A/B of igemm_pl_as.h)

@@ -92,6 +92,10 @@ def main():
                 if args.step_like:
                     st["res"] = ops.pl_split(torch.randn(*yp.shape, device=dev))
                     st["add"] = ops.pl_split(torch.randn(*x.shape, device=dev))
+                    # the step hands the ReLU mask of the block input over as BITS (written by the producing epilogue)
+                    xs = ops.pl_join(st["xp"]).reshape(-1, Cin // 8, 8)
+                    st["xp"].mask = ((xs > 0).to(torch.int32) << torch.arange(8, device=dev).to(torch.int32)).sum(-1).to(torch.uint8)
+                    del xs
                 sets.append(st)
             it = [0]
 
@@ -101,7 +105,7 @@ def main():
 
             def f_fwd():
                 s_ = nxt()
-                ops.pl_conv_fwd_raw(s_["xp"], wp, sc, bi, s_["res"], stride, pad, True)
+                ops.pl_conv_fwd_raw(s_["xp"], wp, sc, bi, s_["res"], stride, pad, True, want_mask=args.step_like)
 
             def f_dgrad():
                 s_ = nxt()

@@ -2,7 +2,7 @@
 # Round artifacts on the GPU box: full GPU test-suite, smoke, the bench line, rocprofv3 kernel stats, PMC HBM traffic +
 # MFMA utilisation (own passes), device timeline, host profile / phase times, step-like GEMM table, comm-mode lines.
 # Everything lands under gpurun_out/$TAG; the summaries worth judging are copied into profiles/ afterwards.
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/$TAG
 mkdir -p $O
 R=$PWD
@@ -24,8 +24,17 @@ P='import json,sys; d=json.loads(sys.stdin.readline()); print({k:d.get(k) for k 
   timeout 300 $B --steps 10 --warmup 3 --no-profile --hoist-loss-plan 2>&1 | tail -1 | python -c "$P"
   timeout 300 $B --steps 10 --warmup 3 --no-profile --no-auto-graph --config C1 2>&1 | tail -1 | python -c "$P"
 } > $O/bench_variants.log 2>&1; cat $O/bench_variants.log
-timeout 300 python tools/host_profile.py 2>&1 | grep -v amdgpu.ids | head -40 > $O/host_profile.log
-timeout 300 python tools/phase_times.py 2>&1 | grep -v amdgpu.ids | tail -6 >> $O/host_profile.log; tail -6 $O/host_profile.log
+# host profile of the bench mode with launch plans ON: the untraced node timeline (events between the autograd nodes of the
+# replayed step) + the per-phase table of tools/phase_times.py (default mode = the bench mode) + the Python-side profile
+{ echo "## tools/node_times.py (C3, bf16x6p, plans on, untraced: HIP events between the nodes of the replayed step)"
+  timeout 300 python tools/node_times.py 2>&1 | grep -v amdgpu.ids | tail -40
+  echo "## tools/node_times.py --config C1 (same launches, ~no GPU work)"
+  timeout 300 python tools/node_times.py --config C1 2>&1 | grep -v amdgpu.ids | tail -40
+  echo "## tools/phase_times.py (bench mode, plans on)"
+  timeout 300 python tools/phase_times.py 2>&1 | grep -v amdgpu.ids | tail -12
+  echo "## tools/host_profile.py"
+  timeout 300 python tools/host_profile.py 2>&1 | grep -v amdgpu.ids | head -40
+} > $O/host_profile.log 2>&1; grep -A12 "phase_times" $O/host_profile.log | head -14
 timeout 300 python tools/bench_gemm.py --mma bf16x6p --step-like 2>&1 | grep -v amdgpu.ids > $O/plane_gemm_steplike.log; tail -3 $O/plane_gemm_steplike.log
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- $B --steps 3 --warmup 1 > /dev/null 2>&1
@@ -42,5 +51,5 @@ python tools/pmc_traffic.py /tmp/pmc_f_$TAG /tmp/pmc_w_$TAG > $O/hbm_traffic.jso
 python tools/pmc_mfma_util.py /tmp/pmc_m_$TAG > $O/mfma_util.json
 python tools/timeline.py /tmp/tl_$TAG > $O/timeline.log
 head -c 600 $O/mfma_util.json; echo; head -c 500 $O/hbm_traffic.json; echo; head -5 $O/timeline.log; head -8 $O/bench_kernel_stats.csv | cut -c1-160
-# per-tensor gradient error of the two plane arithmetics against the oracle's fp64 run at the benchmark size (full tensors; ~5 min of host time)
-timeout 1200 python tools/grad_error_report.py --config C3 --modes f16x3p,bf16x6p --out $O/grad_error_C3_f16x3p_bf16x6p.json > $O/grad_error.log 2>&1; grep -E "^==|backbone|ground_|input_proj" $O/grad_error.log | cut -c1-200 | head -30
+# per-tensor gradient error of the bench arithmetic against the oracle's fp64 run at the benchmark size (full tensors; ~3 min of host time)
+timeout 1200 python tools/grad_error_report.py --config C3 --modes bf16x6p --out $O/grad_error_C3_bf16x6p.json > $O/grad_error.log 2>&1; grep -E "^==|backbone|ground_|input_proj" $O/grad_error.log | cut -c1-200 | head -30
