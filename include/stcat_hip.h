@@ -127,17 +127,21 @@ int stcat_pl_conv_dgrad(const void* gh, const void* gl, const void* th, const vo
 int stcat_pl_conv_dgrad_cadd(const void* gh, const void* gl, const void* th, const void* tl, const void* addch,
                              const void* addcl, int add_stride, const unsigned char* ybits, const float* mask_scale,
                              void* dxh, void* dxl, int n, int H, int W, int Cin, int Cout, void* stream);
-/* Linear layers on the plane kernels: the FFN's `dropout(relu(linear1 x))` (modal_encoder.py:239-240) with plane operands
- * (stcat_pl_split of the LayerNorm output; weight planes from stcat_weight_planes_multi on W viewed as [N,1,1,K]) and an
- * fp32 result: yf [M,N] = dropout_p(relu?(x w^T + bias)), ymask (optional) = the bit mask yf > 0 ([M][N/8] bytes).  The
- * dropout decision of element (m, n) is counter drop_offset + m * N + n, as stcat_dropout draws it on [M,N]. */
-int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* bias, float* yf,
-                        unsigned char* ymask, int M, int N, int K, int relu, float drop_p, long drop_seed, long drop_offset,
-                        const long* drop_base, void* stream);
-/* ... and the data gradient of linear2 with that pair's backward in its epilogue: dxf [M,K] = [ybits] mask_scale[k]
- * (g [M,N] . w [N,K]); th / tl = the transposed weight planes [K][N]; ybits = the forward's ymask, mask_scale = 1/(1-p). */
+/* Linear layers on the plane kernels (the spatial encoder layers' FFN, modal_encoder.py:239-240) with plane operands
+ * (stcat_pl_split of the LayerNorm output / the previous plane result; weight planes from stcat_weight_planes_multi on W
+ * viewed as [N,1,1,K]): y [M,N] = dropout_p(relu?(x w^T + bias + addf)) written as fp32 (yf) and / or as planes (yh, yl);
+ * ymask (optional) = the bit mask y > 0 ([M][N/8] bytes); addf (optional) an fp32 [M,N] term (a residual; a gradient to sum).
+ * The dropout decision of element (m, n) is counter drop_offset + m * N + n, as stcat_dropout draws it on [M,N]. */
+int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* bias, const float* addf,
+                        float* yf, void* yh, void* yl, unsigned char* ymask, int M, int N, int K, int relu, float drop_p,
+                        long drop_seed, long drop_offset, const long* drop_base, void* stream);
+/* ... and the data gradient of linear2 with that pair's backward in its epilogue: dx [M,K] = [ybits] mask_scale[k]
+ * (g [M,N] . w [N,K]) as fp32 (dxf) and / or planes (dxh, dxl); th / tl = the transposed weight planes [K][N]; ybits = the
+ * forward's ymask, mask_scale = 1/(1-p). */
 int stcat_pl_linear_dgrad_mask(const void* gh, const void* gl, const void* th, const void* tl, const unsigned char* ybits,
-                               const float* mask_scale, float* dxf, int M, int N, int K, void* stream);
+                               const float* mask_scale, float* dxf, void* dxh, void* dxl, int M, int N, int K, void* stream);
+/* out [N] (caller-zeroed) += column sums of a plane set [M][N]: the bias gradient where the upstream gradient is planes */
+int stcat_pl_colsum(const void* h, const void* l, float* out, int M, int N, void* stream);
 /* dw (fp32 OHWI, caller-zeroed) += row_scale[co] * sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0.
  * row_scale (optional, [Cout]): a FrozenBN scale folded out of g — dz * scale is never materialised */
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,

@@ -72,8 +72,9 @@ SIGNATURES: Dict[str, str] = {
     "stcat_temporal_map_argmax": "pppiis",
     "stcat_pl_conv_fwd": "pppppppppppp" + "iiiiiiiiii" + "s",
     "stcat_pl_conv_dgrad": "ppppppppppppppp" + "iiiiiiiii" + "s",
-    "stcat_pl_linear_fwd": "ppppp" + "pp" + "iiii" + "fllp" + "s",
-    "stcat_pl_linear_dgrad_mask": "pppp" + "pp" + "p" + "iii" + "s",
+    "stcat_pl_linear_fwd": "ppppp" + "p" + "ppp" + "p" + "iiii" + "fllp" + "s",
+    "stcat_pl_linear_dgrad_mask": "pppp" + "pp" + "ppp" + "iii" + "s",
+    "stcat_pl_colsum": "pppiis",
     "stcat_pl_conv_dgrad_cadd": "pppppp" + "i" + "pppp" + "iiiii" + "s",
     "stcat_pl_conv_wgrad": "pppppp" + "iiiiiiiii" + "s",
     "stcat_pl_maxpool3x3s2": "pppiiiis",

@@ -89,7 +89,7 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
                 gp = ops.pl_split(g)
                 dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
                 L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, wtp.h, wtp.l, ybits.data_ptr(), gainvec.data_ptr(),
-                       dx.data_ptr(), M, N, K, st)
+                       dx.data_ptr(), None, None, M, N, K, st)
             elif mask is not None:
                 my, gain = mask
                 dx = torch.empty(M, K, device=g.device, dtype=torch.float32)
@@ -168,11 +168,15 @@ def wgrad_flush(like: torch.Tensor) -> None:
         for args, _, _ in pending:
             if args[0] == "multi":
                 ops.linear_wgrad_multi(*args[1:])
+            elif args[0] == "call":
+                args[1]()
             else:
                 L.call("stcat_linear_wgrad", *args, st)
     for args, g, x2 in pending:
         if args[0] == "multi":
             wg.keep(*args[1], *args[2])
+        elif args[0] == "call":
+            wg.keep(*args[2])
         else:
             wg.keep(g, x2)
     _DIRTY[0] = True
@@ -271,6 +275,7 @@ FUSE_FFN = not os.environ.get("STCAT_NO_FFN_FUSE")
 
 
 FFN_PLANES = not os.environ.get("STCAT_NO_FFN_PLANES")
+FFN_PLANES_FULL = not os.environ.get("STCAT_NO_FFN_PLANES_FULL")    # (linear2 and both weight gradients on the plane kernels too)
 
 
 class FfnPlanes:
@@ -283,13 +288,14 @@ class FfnPlanes:
         self.gain = {}
 
     def refresh(self, pairs, need_bwd: bool):
-        """pairs: [(W1 [F, D], W2 [D, F]), ...] -> {id(W1): (planes of W1, transposed planes of W2)}"""
+        """pairs: [(W1 [F, D], W2 [D, F]), ...] -> {W1.data_ptr(): (planes of W1, of W1^T, of W2, of W2^T)}"""
         ws = []
         for W1, W2 in pairs:
             ws.append(W1.view(W1.shape[0], 1, 1, W1.shape[1]))
             ws.append(W2.view(W2.shape[0], 1, 1, W2.shape[1]))
         fwd, tr = self.wp.refresh(ws, transposed=need_bwd)
-        return {W1.data_ptr(): (fwd[W1.data_ptr()], tr.get(W2.data_ptr()) if need_bwd else None) for W1, W2 in pairs}
+        return {W1.data_ptr(): (fwd[W1.data_ptr()], tr.get(W1.data_ptr()) if need_bwd else None, fwd[W2.data_ptr()],
+                                tr.get(W2.data_ptr()) if need_bwd else None) for W1, W2 in pairs}
 
     def gainvec(self, like, n: int, gain: float):
         key = (str(like.device), n, round(gain, 9))
@@ -318,13 +324,28 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p, pl=None):
         gv = pl[1].gainvec(x, N, 1.0 / (1.0 - p) if p > 0.0 else 1.0) if ent is not None else None
         if ent is not None and gv is not None and x2.is_contiguous():
             # linear1 on the A-stationary plane kernel (K = 256 -> N = 2048: its shape), operands as planes
-            w1p, w2t = ent
+            w1p, w1t, w2p, w2t = ent
             xp = ops.pl_split(x2)
-            f1d = torch.empty(M, N, device=x.device, dtype=torch.float32)
             ymask = torch.empty(M, N // 8, device=x.device, dtype=torch.uint8)
             seed, off, base = ops._dropout_stream.take(M * N, x.device) if p > 0.0 else (0, 0, None)
-            L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, L._ptr(b1), f1d.data_ptr(), ymask.data_ptr(), M, N, K, 1,
-                   float(p), seed, off, base, L.stream_of(x2))
+            st_x = L.stream_of(x2)
+            if FFN_PLANES_FULL and W2.shape[0] % 64 == 0:
+                # ... its result stays in planes: linear2 (K = 2048 -> 256) runs on the plane tile kernel, and the backward
+                # pass reads the planes again (linear2's weight gradient); the fp32 [M, 2048] activation is never written
+                hp = ops.Planes.empty(x, M, N)
+                L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, L._ptr(b1), None, None, hp.h, hp.l, ymask.data_ptr(),
+                       M, N, K, 1, float(p), seed, off, base, st_x)
+                D = W2.shape[0]
+                res2 = x.reshape(M, D)
+                res2 = res2 if res2.is_contiguous() else res2.contiguous()
+                h2 = torch.empty(M, D, device=x.device, dtype=torch.float32)
+                L.call("stcat_pl_linear_fwd", hp.h, hp.l, w2p.h, w2p.l, L._ptr(b2), res2.data_ptr() if p == 0.0 else None,
+                       h2.data_ptr(), None, None, None, M, D, N, 0, 0.0, 0, 0, None, st_x)
+                y, c_n = _f(ops.LayerNormFn, _T, h2.view(*shp[:-1], D), x if p > 0.0 else None, g, be, 1e-5, p)
+                return y, ("planes", c_n, xp, hp, ymask, gv, (w1t, w2t), (W1, W2), p, y.shape)
+            f1d = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, L._ptr(b1), None, f1d.data_ptr(), None, None,
+                   ymask.data_ptr(), M, N, K, 1, float(p), seed, off, base, st_x)
             y, st = _outln_f(f1d.view(*shp[:-1], N), W2, b2, x, g, be, p)
             return y, (st, ("bits", ymask, gv, w2t), x2, f1d, W1)
         if p > 0.0:
@@ -347,6 +368,8 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p, pl=None):
 
 def _ffn_b(st, dy):
     """-> (d_x [M,D], dW1, db1, dW2, db2, dg, dbe)"""
+    if st[0] == "planes":
+        return _ffn_b_planes(st, dy)
     st_o, c_dr, x_1, f1, W1 = st
     if isinstance(c_dr, tuple) and c_dr[0] == "bits":
         d_f1, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy, mask=c_dr)
@@ -359,6 +382,50 @@ def _ffn_b(st, dy):
     d_f1d, d_x_res, dW2, db2, dg, dbe = _outln_b(st_o, dy)
     d_f1 = ops.DropoutFn.backward(c_dr, d_f1d.view(f1.shape))[0] if c_dr is not None else d_f1d
     d_x, dW1, db1, _ = _lin_b(d_f1, x_1, W1, relu_y=f1, add=d_x_res)      # + residual gradient, fused into the dgrad
+    return d_x, dW1, db1, dW2, db2, dg, dbe
+
+
+def _ffn_b_planes(st, dy):
+    """the FFN's backward with every [M, 2048] tensor in planes (round 5): LayerNorm backward (fp32) -> split -> linear2's data
+    gradient with the ReLU + dropout backward from the bit mask (A-stationary kernel, planes out) -> linear1's data gradient
+    (plane tile kernel, K = 2048, fp32 out + the residual gradient); both weight gradients on the plane weight-gradient kernel,
+    the bias gradients as column sums — all four on the weight-gradient stream."""
+    _, c_n, xp, hp, ymask, gv, (w1t, w2t), (W1, W2), p, shp = st
+    r = ops.LayerNormFn.backward(c_n, dy.reshape(shp))
+    d_h, d_res, dg, dbe = r[0], r[1], r[2], r[3]
+    if p == 0.0:
+        d_res = d_h
+    F, D = W1.shape
+    d_h2 = d_h.reshape(-1, D)
+    d_h2 = d_h2 if d_h2.is_contiguous() else d_h2.contiguous()
+    M = d_h2.shape[0]
+    stx = L.stream_of(d_h2)
+    gp = ops.pl_split(d_h2)
+    d_f1 = ops.Planes.empty(d_h2, M, F)
+    L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, w2t.h, w2t.l, ymask.data_ptr(), gv.data_ptr(), None, d_f1.h, d_f1.l,
+           M, D, F, stx)
+    add = d_res.reshape(M, D)
+    add = add if add.is_contiguous() else add.contiguous()
+    d_x = torch.empty(M, D, device=d_h2.device, dtype=torch.float32)
+    L.call("stcat_pl_linear_fwd", d_f1.h, d_f1.l, w1t.h, w1t.l, None, add.data_ptr(), d_x.data_ptr(), None, None, None,
+           M, D, F, 0, 0.0, 0, 0, None, stx)
+    dW1, db1 = ops._zeros(d_h2, F, D), ops._zeros(d_h2, F)
+    dW2, db2 = ops._zeros(d_h2, D, F), ops._zeros(d_h2, D)
+
+    def view4(pl, C):
+        return ops.Planes(pl.t.view(pl.t.shape[0], 1, 1, M, C))
+
+    def wgrads():
+        ops.pl_conv_wgrad_raw(view4(gp, D), view4(hp, F), (D, 1, 1, F), 1, 0, out=dW2.view(D, 1, 1, F))
+        ops.pl_conv_wgrad_raw(view4(d_f1, F), view4(xp, D), (F, 1, 1, D), 1, 0, out=dW1.view(F, 1, 1, D))
+        L.call("stcat_colsum", d_h2.data_ptr(), None, db2.data_ptr(), M, D, L.stream_of(d_h2))
+        L.call("stcat_pl_colsum", d_f1.h, d_f1.l, db1.data_ptr(), M, F, L.stream_of(d_h2))
+
+    keep = (gp.t, hp.t, d_f1.t, xp.t, d_h2)
+    if _BATCH and _BATCH[-1] is not None and DEFER_WGRADS:
+        _BATCH[-1].append((("call", wgrads, keep), gp.t, hp.t))
+    else:
+        wgrads()
     return d_x, dW1, db1, dW2, db2, dg, dbe
 
 

@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(NW * 64, 2) igemm_pl_fwd_kernel(PlParams p) {
         if (p.Rh) {
           STCAT_UNROLL
           for (int e = 0; e < 8; ++e) x[e] += stcat_join1<NP, F16>(cur.r[ps], e);
-        } else if (F32 && p.Rf) {
+        } else if (p.Rf) {          // fp32 residual: the exact-fp32 form, and the Linear layers on the plane kernels
           const float4 r0 = stcat_ld4(p.Rf + (long)m * p.ldr + n), r1 = stcat_ld4(p.Rf + (long)m * p.ldr + n + 4);
           x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
         }
@@ -783,6 +783,39 @@ static __device__ __forceinline__ void stcat_load_planes(const __bf16* h, const 
   }
 }
 // 3x3 stride-2 pad-1 max-pool, NHWC fp32 in (stem output) -> planes out (input of layer1)
+// out[n] += sum_m (hi + mid + lo)[m][n]: the bias gradient of a Linear whose upstream gradient only exists as planes
+// (encoder FFN linear1, round 5).  Block = 32 column groups of 8 x 8 row lanes; grid (row chunks, N / 256).
+__global__ void __launch_bounds__(256) pl_colsum_kernel(const __bf16* h, const __bf16* l, float* out, int M, int N, int np,
+                                                        int rows_per_block) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.y * 256 + cg * 8;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (int m = m0 + rl; m < m1; m += 8) {
+      STCAT_UNROLL
+      for (int pi = 0; pi < 3; ++pi) {
+        if (pi < np) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(stcat_plane(h, l, pi) + (long)m * N + n);
+          STCAT_UNROLL
+          for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+      }
+    }
+  }
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.y * 256 + c < N) {
+    float v = 0.f;
+    STCAT_UNROLL
+    for (int r = 0; r < 8; ++r) v += red[r][c];
+    atomicAdd(out + blockIdx.y * 256 + c, v);
+  }
+}
+
 __global__ void __launch_bounds__(256) maxpool3x3s2_pl_kernel(const float* x, __bf16* yh, __bf16* yl, int n, int H, int W,
                                                              int C, int OH, int OW, int np) {
   const int c8n = C / 8;

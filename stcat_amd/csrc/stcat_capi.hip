@@ -418,7 +418,7 @@ bool pl_as_ok(const PlParams& p) {
   const IgemmGeom& g = p.g;
   if (g.KH != 1 || g.KW != 1 || g.mul != 1 || g.div != 1 || g.off != 0 || p.par) return false;
   if (!(p.K == 64 || p.K == 128 || p.K == 256) || p.K != g.C || p.N % 64 != 0 || p.N < 4 * 64) return false;
-  if (p.C2h || (p.Yh && !p.Mi) || p.radd_div > 1 || p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return false;
+  if (p.C2h || p.Rf || (p.Yh && !p.Mi) || p.radd_div > 1 || p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return false;
   if ((long)p.M * g.ld * 2 >= 0x7FFFFFFFl) return false;          // 32-bit byte offsets of the fragment loads
   return g_pl_force == 7 || (long)p.M * p.N >= (1l << 22);         // (small problems: the tile kernel's finer grid)
 }
@@ -1458,15 +1458,18 @@ int stcat_pl_conv_dgrad_cadd(const void* gh, const void* gl, const void* th, con
 // N = 2048 at 13 248 rows) is exactly the A-stationary kernel's shape; operands arrive as planes (stcat_pl_split of the
 // LayerNorm output / the upstream gradient: 10 us), results leave as fp32 for the consumers that stay on fp32 tensors.
 // y = dropout_p(relu?(x w^T + bias)) [M, N] fp32 (+ the bit mask y > 0 for the backward pass)
-int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* bias, float* yf,
-                        unsigned char* ymask, int M, int N, int K, int relu, float drop_p, long drop_seed, long drop_offset,
-                        const long* drop_base, void* stream) {
+int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const void* wl, const float* bias, const float* addf,
+                        float* yf, void* yh, void* yl, unsigned char* ymask, int M, int N, int K, int relu, float drop_p,
+                        long drop_seed, long drop_offset, const long* drop_base, void* stream) {
   if (K % 32 != 0 || N % 64 != 0 || M <= 0) return fail("pl_linear_fwd: need K %% 32 == 0, N %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
-  if (!aligned16(xh) || !aligned16(xl) || !aligned16(wh) || !aligned16(wl) || !yf) return fail("pl_linear_fwd: planes must be 16-byte aligned, yf set");
+  if (!aligned16(xh) || !aligned16(xl) || !aligned16(wh) || !aligned16(wl)) return fail("pl_linear_fwd: planes must be 16-byte aligned");
+  if (!yf && !yh) return fail("pl_linear_fwd: no output (yf and yh both null)");
+  if ((yh != nullptr) != (yl != nullptr) || !aligned16(yh) || !aligned16(yl) || !aligned16(yf) || !aligned16(addf))
+    return fail("pl_linear_fwd: yh / yl go together; outputs and addf 16-byte aligned");
   if (g_mma_mode_raw < 4) return fail("pl_linear_fwd: plane modes only");
   PlParams p = {};
   p.Ah = (const __bf16*)xh; p.Al = (const __bf16*)xl; p.Bh = (const __bf16*)wh; p.Bl = (const __bf16*)wl;
-  p.Cf = yf; p.Mo = ymask; p.bias = bias; p.relu = relu;
+  p.Cf = yf; p.Ch = (__bf16*)yh; p.Cl = (__bf16*)yl; p.Mo = ymask; p.bias = bias; p.relu = relu; p.Rf = addf;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   p.a_bytes = plane_bytes((long)M * K); p.b_bytes = plane_bytes((long)N * K);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_linear_fwd: a plane exceeds 2 GB");
@@ -1475,16 +1478,17 @@ int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const vo
   p.g = conv_geom_fwd(1, M, K, K, 1, M, 1, 1, 1, 0);
   return launch_pl_fwd(p, (hipStream_t)stream);
 }
-
 // dx [M, K] fp32 = [ybits] mask_scale[k] * (g [M, N] . w [N, K]); th / tl = the TRANSPOSED weight planes [K][N]
 int stcat_pl_linear_dgrad_mask(const void* gh, const void* gl, const void* th, const void* tl, const unsigned char* ybits,
-                               const float* mask_scale, float* dxf, int M, int N, int K, void* stream) {
+                               const float* mask_scale, float* dxf, void* dxh, void* dxl, int M, int N, int K, void* stream) {
   if (N % 32 != 0 || K % 64 != 0 || M <= 0) return fail("pl_linear_dgrad_mask: need N %% 32 == 0, K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
-  if (!aligned16(gh) || !aligned16(gl) || !aligned16(th) || !aligned16(tl) || !dxf) return fail("pl_linear_dgrad_mask: planes must be 16-byte aligned, dxf set");
+  if (!aligned16(gh) || !aligned16(gl) || !aligned16(th) || !aligned16(tl)) return fail("pl_linear_dgrad_mask: planes must be 16-byte aligned");
+  if ((!dxf && !dxh) || (dxh != nullptr) != (dxl != nullptr) || !aligned16(dxh) || !aligned16(dxl) || !aligned16(dxf))
+    return fail("pl_linear_dgrad_mask: need dxf and / or the plane pair dxh + dxl, 16-byte aligned");
   if (g_mma_mode_raw < 4) return fail("pl_linear_dgrad_mask: plane modes only");
   PlParams p = {};
   p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)th; p.Bl = (const __bf16*)tl;
-  p.Cf = dxf; p.Mi = ybits; p.mscale = mask_scale;
+  p.Cf = dxf; p.Ch = (__bf16*)dxh; p.Cl = (__bf16*)dxl; p.Mi = ybits; p.mscale = mask_scale;
   p.a_bytes = plane_bytes((long)M * N); p.b_bytes = plane_bytes((long)N * K);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_linear_dgrad_mask: a plane exceeds 2 GB");
   p.ldb = N; p.b_tap_stride = (unsigned)((long)K * N);
@@ -1508,6 +1512,17 @@ int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const vo
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_wgrad: a plane exceeds 2 GB");
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
   return launch_pl_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
+}
+
+// out[n] (caller-zeroed) += sum over rows of the plane set [M][N]
+int stcat_pl_colsum(const void* h, const void* l, float* out, int M, int N, void* stream) {
+  if (M <= 0 || N <= 0 || N % 8 != 0 || !aligned16(h) || !aligned16(l)) return fail("pl_colsum: M=%d N=%d (N %% 8 == 0, planes 16-byte aligned)", M, N);
+  if (g_mma_mode_raw < 4) return fail("pl_colsum: plane modes only");
+  int rows = cdiv(M, 256);
+  if (rows < 32) rows = 32;
+  STCAT_LAUNCH(pl_colsum_kernel, dim3(cdiv(M, rows), cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)h,
+               (const __bf16*)l, out, M, N, pl_np_arg(), rows);
+  return launch_status();
 }
 
 int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int W, int C, void* stream) {
@@ -1721,6 +1736,7 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_pl_conv_dgrad_cadd),
     STCAT_PLAN_FN(stcat_pl_linear_fwd),
     STCAT_PLAN_FN(stcat_pl_linear_dgrad_mask),
+    STCAT_PLAN_FN(stcat_pl_colsum),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad),
     STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),
     STCAT_PLAN_FN(stcat_pl_split),

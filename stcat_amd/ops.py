@@ -1411,6 +1411,14 @@ def pl_join(p: Planes) -> torch.Tensor:
     return out
 
 
+def pl_colsum(p: Planes) -> torch.Tensor:
+    """column sums of a 2-D plane set [M, N] -> fp32 [N] (a bias gradient whose upstream gradient only exists as planes)"""
+    M, N = p.shape
+    out = _zeros(p.t, N)
+    L.call("stcat_pl_colsum", p.h, p.l, out.data_ptr(), M, N, L.stream_of(p.t))
+    return out
+
+
 def pl_maxpool_raw(x: torch.Tensor) -> Planes:
     n, H, W, C = x.shape
     OH, OW = conv_out_hw(H, W, 3, 2, 1)

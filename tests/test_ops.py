@@ -402,6 +402,7 @@ def _pl_linear_ffn(dev, big):
             w1 = rnd(N, K, seed=2, scale=K ** -0.5).to(dev)
             b1 = rnd(N, seed=3).to(dev)
             w2 = rnd(K, N, seed=4, scale=N ** -0.5).to(dev)             # linear2: [D, F]
+            b2 = rnd(K, seed=7).to(dev)
             fwd, tr = ops.WeightPlanes().refresh([w1.view(N, 1, 1, K), w2.view(K, 1, 1, N)], transposed=True)
             w1p, w2t = fwd[w1.data_ptr()], tr[w2.data_ptr()]
             xp = ops.pl_split(x)
@@ -411,8 +412,10 @@ def _pl_linear_ffn(dev, big):
             seed, off, base = ops._dropout_stream.take(M * N, x.device) if p > 0 else (0, 0, None)
             L.call("stcat_debug_force_pl_tile", 7 if not big else -1)
             try:
-                L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, b1.data_ptr(), y.data_ptr(), bits.data_ptr(), M, N, K, 1,
-                       float(p), seed, off, base, L.stream_of(x))
+                yp = ops.Planes.empty(x, M, N)                             # fp32 AND plane output of the same launch
+                L.call("stcat_pl_linear_fwd", xp.h, xp.l, w1p.h, w1p.l, b1.data_ptr(), None, y.data_ptr(), yp.h, yp.l,
+                       bits.data_ptr(), M, N, K, 1, float(p), seed, off, base, L.stream_of(x))
+                assert torch.equal(ops.pl_join(yp), y), "pl_linear_fwd: planes == fp32 result"
                 ref = torch.relu(x.cpu().double() @ w1.cpu().double().t() + b1.cpu().double())
                 if p > 0:
                     keep = torch.from_numpy(ops.dropout_keep_mask(seed, off + int(ops._dropout_stream.base(x.device).item()), M * N, p))
@@ -425,12 +428,34 @@ def _pl_linear_ffn(dev, big):
                 gain = 1.0 / (1.0 - p)
                 gv = torch.full((N,), gain, device=dev)
                 dx = torch.empty(M, N, device=dev)
-                L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, w2t.h, w2t.l, bits.data_ptr(), gv.data_ptr(), dx.data_ptr(), M, K, N,
-                       L.stream_of(x))
+                dxp = ops.Planes.empty(x, M, N)
+                L.call("stcat_pl_linear_dgrad_mask", gp.h, gp.l, w2t.h, w2t.l, bits.data_ptr(), gv.data_ptr(), dx.data_ptr(),
+                       dxp.h, dxp.l, M, K, N, L.stream_of(x))
+                assert torch.equal(ops.pl_join(dxp), dx), "pl_linear_dgrad_mask: planes == fp32 result"
             finally:
                 L.call("stcat_debug_force_pl_tile", -1)
             refd = (g.cpu().double() @ w2.cpu().double()) * (y.cpu() > 0) * gain
             close(dx, refd.float(), 2e-5, f"pl_linear_dgrad_mask M{M}")
+            # the narrow side on the plane tile kernel: linear2 (K = N_wide -> D) with bias and an fp32 term, from the planes
+            w2p, w1t = fwd[w2.data_ptr()], tr[w1.data_ptr()]
+            addf = rnd(M, K, seed=8).to(dev)
+            y2 = torch.empty(M, K, device=dev)
+            L.call("stcat_pl_linear_fwd", yp.h, yp.l, w2p.h, w2p.l, b2.data_ptr(), addf.data_ptr(), y2.data_ptr(), None, None,
+                   None, M, K, N, 0, 0.0, 0, 0, None, L.stream_of(x))
+            ref2 = y.cpu().double() @ w2.cpu().double().t() + b2.cpu().double() + addf.cpu().double()
+            close(y2, ref2.float(), 2e-5, f"pl_linear_fwd narrow M{M}")
+            # linear1's data gradient from the plane gradient (transposed planes of W1), and both weight gradients + column sums
+            dx1 = torch.empty(M, K, device=dev)
+            L.call("stcat_pl_linear_fwd", dxp.h, dxp.l, w1t.h, w1t.l, None, None, dx1.data_ptr(), None, None, None,
+                   M, K, N, 0, 0.0, 0, 0, None, L.stream_of(x))
+            close(dx1, (dx.cpu().double() @ w1.cpu().double()).float(), 2e-5, f"linear1 dgrad on planes M{M}")
+            if N % 128 == 0 and K % 128 == 0:
+                v4 = lambda pl, C: ops.Planes(pl.t.view(pl.t.shape[0], 1, 1, M, C))   # noqa: E731
+                dW2 = ops.pl_conv_wgrad_raw(v4(gp, K), v4(yp, N), (K, 1, 1, N), 1, 0).view(K, N)
+                close(dW2, (g.cpu().double().t() @ y.cpu().double()).float(), 2e-5, f"linear2 wgrad on planes M{M}")
+                dW1 = ops.pl_conv_wgrad_raw(v4(dxp, N), v4(xp, K), (N, 1, 1, K), 1, 0).view(N, K)
+                close(dW1, (dx.cpu().double().t() @ x.cpu().double()).float(), 2e-5, f"linear1 wgrad on planes M{M}")
+            close(ops.pl_colsum(dxp), dx.cpu().double().sum(0).float(), 2e-5, f"pl_colsum M{M}")
     finally:
         L.set_mma_mode(old_mode)
 
