@@ -146,6 +146,12 @@ int stcat_pl_colsum(const void* h, const void* l, float* out, int M, int N, void
  * row_scale (optional, [Cout]): a FrozenBN scale folded out of g — dz * scale is never materialised */
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
                         int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* the same with a caller-owned workspace of ws_floats fp32 values (one per stream: launches on a stream reuse it in order):
+ * when (reduction slices) x Cout x KH KW Cin values fit, the slices STORE their partial tiles and a second launch sums them in
+ * slice order — no atomics, dw bit-identical run to run; otherwise the atomic form */
+int stcat_pl_conv_wgrad_ws(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
+                           int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                           long ws_floats, void* stream);
 /* resnet maxpool 3x3/2 pad 1: fp32 NHWC in (stem output) -> planes out */
 int stcat_pl_maxpool3x3s2(const float* x, void* yh, void* yl, int n, int H, int W, int C, void* stream);
 /* fp32 <-> planes; n % 8 == 0 */

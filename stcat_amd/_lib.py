@@ -77,6 +77,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_pl_colsum": "pppiis",
     "stcat_pl_conv_dgrad_cadd": "pppppp" + "i" + "pppp" + "iiiii" + "s",
     "stcat_pl_conv_wgrad": "pppppp" + "iiiiiiiii" + "s",
+    "stcat_pl_conv_wgrad_ws": "pppppp" + "iiiiiiiii" + "pl" + "s",
     "stcat_pl_maxpool3x3s2": "pppiiiis",
     "stcat_pl_split": "pppls",
     "stcat_pl_join": "pppls",

@@ -56,6 +56,8 @@ struct PlParams {
   const float* Yf;                      // dgrad mask source y [M][ldc]
   float* C2f;                           // second scaled output
   float* Wf;                            // wgrad: fp32 output dW [rows][ldc] (atomics into a zeroed buffer)
+  float* Ws;                            // wgrad: optional workspace [slices][rows][ldc]: every reduction slice STORES its partial
+                                        // tile there (no atomics) and pl_wgrad_reduce_kernel sums the slices in order into Wf
   const float* wscale;                  // wgrad: optional per-row factor dW[m][:] *= wscale[m] (a FrozenBN scale folded out of dY)
   float acc_mul;                        // the accumulator is multiplied by this before scale / bias (fwd, dgrad) or before
                                         // the atomics (wgrad): 1, or 2^-k undoing the operand scales of mode f16x3p
@@ -606,7 +608,7 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
   const int red0 = zsl * p.k_chunk;
   const int red1 = min(p.K, red0 + p.k_chunk);
   const int nk = (red1 - red0 + BK - 1) / BK;
-  if (nk <= 0) return;
+  if (nk <= 0 && !p.Ws) return;          // (with a workspace every slice stores its tile: an empty slice stores zeros)
   const int ohw = g.OH * g.OW;
 
   // DMA: piece q = wave + 8 i of a plane covers bytes [1024 q, 1024 q + 1024) of the [32][ROW] image: k-row
@@ -737,10 +739,25 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         const float v_ = (p.wscale ? acc[tm][tn][r] * p.wscale[m] : acc[tm][tn][r]) * p.acc_mul;
-        if (!((p.debug & 1) && v_ != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], v_);
+        if (p.Ws) p.Ws[((long)zsl * p.M + m) * p.ldc + n] = v_;
+        else if (!((p.debug & 1) && v_ != 12345.f)) atomicAdd(&p.Wf[(long)m * p.ldc + n], v_);
       }
     }
   }
+}
+
+// dW[i] += sum over the reduction slices, IN SLICE ORDER, of the partial tiles the weight-gradient workgroups stored (round 5):
+// no atomics — the sum's order is fixed, so the gradient is bit-identical run to run — and the 8.4 M contended atomic adds of
+// a layer3 1x1 launch (8-14 % of its time) become 34 MB of streaming stores + this pass
+__global__ void __launch_bounds__(256) pl_wgrad_reduce_kernel(const float* ws, float* out, long n4, int slices, long stride) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = stcat_ld4(out + i * 4);
+  for (int s_ = 0; s_ < slices; ++s_) {
+    const float4 v = stcat_ld4(ws + (long)s_ * stride + i * 4);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  stcat_st4(out + i * 4, a);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -576,7 +576,7 @@ int launch_pl_fwd_f32(const IgemmParams& s, hipStream_t st) {
 }
 
 // rows = Cout, cols = taps * Cin, red = pixels
-int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
+int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st, float* ws = nullptr, long ws_floats = 0) {
   if (rows % 128 != 0 || p.g.C % 128 != 0) return fail("plane wgrad: need Cout, Cin %% 128 == 0 (%d, %d)", rows, p.g.C);
   const int BM = (rows % 256 == 0 && g_pl_force != 3) ? 256 : 128;
   // (three planes: BM + BN <= 384, the 256 x 256 tile does not fit)
@@ -598,24 +598,37 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st) {
   p.M = rows; p.N = cols; p.K = red; p.k_chunk = chunk; p.debug = g_pl_debug;
   p.acc_mul = g_pl_f16 ? ldexpf(1.f, -g_f16_glog) : 1.f;     // mode f16x3p: dY planes hold dy * 2^glog, X planes are unscaled
   const dim3 grid(tiles, 1, nsplit);
+  // atomics-free form: the slices store partial tiles, one more launch sums them in order (bit-reproducible)
+  const long out_floats = (long)rows * p.ldc;
+  const bool use_ws = ws && nsplit > 1 && (long)nsplit * out_floats <= ws_floats && out_floats % 4 == 0 && aligned16(ws) &&
+                      aligned16(p.Wf) && !(g_pl_debug & 0x4000);
+  p.Ws = use_ws ? ws : nullptr;
+  auto finish = [&]() -> int {
+    if (int rc = launch_status()) return rc;
+    if (!use_ws) return 0;
+    const long n4 = out_floats / 4;
+    STCAT_LAUNCH(pl_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.Wf, n4,
+                 nsplit, out_floats);
+    return launch_status();
+  };
   if (g_pl_f16) {
     if (BM == 256 && BN == 256) STCAT_PLH_WGRAD(256, 256, 2, 4, grid)
     else if (BM == 256) STCAT_PLH_WGRAD(256, 128, 4, 2, grid)
     else if (BN == 256) STCAT_PLH_WGRAD(128, 256, 2, 4, grid)
     else STCAT_PLH_WGRAD(128, 128, 2, 4, grid)
-    return launch_status();
+    return finish();
   }
   if (g_pl_np == 3) {
     if (BM == 256) STCAT_PL3_WGRAD(256, 128, 4, 2, grid)
     else if (BN == 256) STCAT_PL3_WGRAD(128, 256, 2, 4, grid)
     else STCAT_PL3_WGRAD(128, 128, 2, 4, grid)
-    return launch_status();
+    return finish();
   }
   if (BM == 256 && BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 256, 2, 4, grid)
   else if (BM == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 256, 128, 4, 2, grid)
   else if (BN == 256) STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 128, 256, 2, 4, grid)
   else STCAT_PL_LAUNCH(igemm_pl_wgrad_kernel, 128, 128, 2, 4, grid)
-  return launch_status();
+  return finish();
 }
 
 inline unsigned plane_bytes(long elems) { return elems * 2 >= 0x7FFFFFFFl ? 0xFFFFFFFFu : (unsigned)(elems * 2); }
@@ -1504,6 +1517,14 @@ int stcat_pl_linear_dgrad_mask(const void* gh, const void* gl, const void* th, c
 
 int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
                         int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  return stcat_pl_conv_wgrad_ws(gh, gl, xh, xl, dw, row_scale, n, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, 0, stream);
+}
+
+// ... with a workspace of ws_floats fp32 values: when the launch's slices x Cout x KH KW Cin partial tiles fit, no atomics are
+// used and dw is bit-identical run to run; else (or ws null) the atomic form above
+int stcat_pl_conv_wgrad_ws(const void* gh, const void* gl, const void* xh, const void* xl, float* dw, const float* row_scale,
+                           int n, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                           long ws_floats, void* stream) {
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   PlParams p = {};
   p.Ah = (const __bf16*)gh; p.Al = (const __bf16*)gl; p.Bh = (const __bf16*)xh; p.Bl = (const __bf16*)xl;
@@ -1511,7 +1532,7 @@ int stcat_pl_conv_wgrad(const void* gh, const void* gl, const void* xh, const vo
   p.a_bytes = plane_bytes((long)n * OH * OW * Cout); p.b_bytes = plane_bytes((long)n * H * W * Cin);
   if (p.a_bytes == 0xFFFFFFFFu || p.b_bytes == 0xFFFFFFFFu) return fail("pl_conv_wgrad: a plane exceeds 2 GB");
   p.g = conv_geom_fwd(H, W, Cin, Cin, OH, OW, KH, KW, stride, pad);
-  return launch_pl_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream);
+  return launch_pl_wgrad(p, Cout, KH * KW * Cin, n * OH * OW, (hipStream_t)stream, ws, ws_floats);
 }
 
 // out[n] (caller-zeroed) += sum over rows of the plane set [M][N]
@@ -1738,6 +1759,7 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_pl_linear_dgrad_mask),
     STCAT_PLAN_FN(stcat_pl_colsum),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad),
+    STCAT_PLAN_FN(stcat_pl_conv_wgrad_ws),
     STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),
     STCAT_PLAN_FN(stcat_pl_split),
     STCAT_PLAN_FN(stcat_pl_join),

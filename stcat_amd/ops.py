@@ -1483,9 +1483,37 @@ def pl_conv_wgrad_raw(g: Planes, x: Planes, w_shape_ohwi, stride, pad, row_scale
     Cout, KH, KW, _ = w_shape_ohwi
     dw = _zeros(g.t, Cout, KH, KW, Cin) if out is None else out
     assert dw.is_contiguous() and tuple(dw.shape) == (Cout, KH, KW, Cin)
-    L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), L._ptr(row_scale), n, H, W, Cin, Cout, KH, KW,
-           stride, pad, L.stream_of(g.t))
+    st = L.stream_of(g.t)
+    ws = _wgrad_workspace(g.t.device, st)
+    if ws is not None:
+        L.call("stcat_pl_conv_wgrad_ws", g.h, g.l, x.h, x.l, dw.data_ptr(), L._ptr(row_scale), n, H, W, Cin, Cout, KH, KW,
+               stride, pad, ws.data_ptr(), ws.numel(), st)
+    else:
+        L.call("stcat_pl_conv_wgrad", g.h, g.l, x.h, x.l, dw.data_ptr(), L._ptr(row_scale), n, H, W, Cin, Cout, KH, KW,
+               stride, pad, st)
     return dw
+
+
+# Workspace of the atomics-free plane weight gradient (csrc/igemm_pl.h: pl_wgrad_reduce_kernel): one buffer per (device,
+# stream) — launches of one stream use it one after the other.  96 MB covers every layer of the backbone at C3 (the largest:
+# 28 slices x 256 x 2304 values = 66 MB) and the encoder FFN; a launch that needs more falls back to atomics.  Created by
+# the first EAGER call on a stream (a launch-plan recording cannot allocate persistent memory; its eager pass comes first).
+WGRAD_WS_FLOATS = int(os.environ.get("STCAT_WGRAD_WS_MB", "96")) * (1 << 18)
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device, stream):
+    if WGRAD_WS_FLOATS <= 0 or device.type != "cuda":
+        key = (str(device), 0)
+    else:
+        key = (str(device), int(stream) if stream is not None else 0)
+    ws = _WGRAD_WS.get(key)
+    if ws is None and WGRAD_WS_FLOATS > 0:
+        if L.RECORDER is not None:
+            return None
+        ws = _WGRAD_WS[key] = torch.empty(WGRAD_WS_FLOATS if device.type == "cuda" else min(WGRAD_WS_FLOATS, 1 << 22),
+                                          device=device, dtype=_f32)
+    return ws
 
 
 def pl_act_bwd_raw(dy: torch.Tensor, y: Optional[torch.Tensor], scale, want_g=True, want_res=False, relu=True):

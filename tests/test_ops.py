@@ -221,6 +221,15 @@ def _pl_conv_body(dev, n, H, W, Cin, Cout, k, stride, pad, relu, res, tile, wgra
                     << torch.arange(8, device=ymask.device).to(torch.int32)).sum(-1).to(torch.uint8)
         dx4, dx5 = ops.pl_conv_dgrad_raw(G, wt, xd.shape, k, stride, pad, add=dx, mask_y=ymp, scale2=msc)  # bit-mask form
         dw = ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad) if wgrad else None
+        if wgrad:
+            # the workspace form (ordered sum of the slices' partial tiles: no atomics) is bit-identical run to run and agrees
+            # with the atomic form (the same launch without a workspace)
+            assert ops._wgrad_workspace(xd.device, L.stream_of(xd)) is not None
+            assert torch.equal(dw, ops.pl_conv_wgrad_raw(G, xp, wd.shape, stride, pad)), "plane wgrad: not bit-reproducible"
+            dw_at = ops._zeros(xd, *wd.shape)
+            L.call("stcat_pl_conv_wgrad", G.h, G.l, xp.h, xp.l, dw_at.data_ptr(), None, n, H, W, Cin, Cout, k, k, stride, pad,
+                   L.stream_of(xd))
+            close(dw_at, dw, 5e-5, "plane wgrad: workspace form vs atomic form")
         gs = ops.pl_scale_raw(G, msc[:1].expand(Cout).contiguous())
         # FrozenBN scale folded into the transposed planes / the weight-gradient epilogue == running on g * scale
         fsc = torch.rand(Cout, device=dev) + 0.5
