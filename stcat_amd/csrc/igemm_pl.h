@@ -750,14 +750,36 @@ __global__ void __launch_bounds__(512) igemm_pl_wgrad_kernel(PlParams p) {
 // no atomics — the sum's order is fixed, so the gradient is bit-identical run to run — and the 8.4 M contended atomic adds of
 // a layer3 1x1 launch (8-14 % of its time) become 34 MB of streaming stores + this pass
 __global__ void __launch_bounds__(256) pl_wgrad_reduce_kernel(const float* ws, float* out, long n4, int slices, long stride) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = stcat_ld4(out + i * 4);
-  for (int s_ = 0; s_ < slices; ++s_) {
-    const float4 v = stcat_ld4(ws + (long)s_ * stride + i * 4);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  // 64 float4 outputs per block x 4 lanes of slices (slice s goes to lane s & 3, each lane sums ITS slices in rising order,
+  // the four lane sums are added in a fixed order): 4 x 4 loads in flight per output — the one-thread-per-output form walked
+  // the slices one load at a time (20 us for 34 MB)
+  __shared__ float4 red[4][64];
+  const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const float* src = ws + i * 4;
+    int s_ = gq;
+    for (; s_ + 12 < slices; s_ += 16) {
+      const float4 v0 = stcat_ld4(src + (long)s_ * stride), v1 = stcat_ld4(src + (long)(s_ + 4) * stride);
+      const float4 v2 = stcat_ld4(src + (long)(s_ + 8) * stride), v3 = stcat_ld4(src + (long)(s_ + 12) * stride);
+      a.x = (((a.x + v0.x) + v1.x) + v2.x) + v3.x; a.y = (((a.y + v0.y) + v1.y) + v2.y) + v3.y;
+      a.z = (((a.z + v0.z) + v1.z) + v2.z) + v3.z; a.w = (((a.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; s_ < slices; s_ += 4) {
+      const float4 v = stcat_ld4(src + (long)s_ * stride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
   }
-  stcat_st4(out + i * 4, a);
+  red[gq][o] = a;
+  __syncthreads();
+  if (gq == 0 && i < n4) {
+    const float4 r0 = red[0][o], r1 = red[1][o], r2 = red[2][o], r3 = red[3][o];
+    float4 d = stcat_ld4(out + i * 4);
+    d.x += (r0.x + r1.x) + (r2.x + r3.x); d.y += (r0.y + r1.y) + (r2.y + r3.y);
+    d.z += (r0.z + r1.z) + (r2.z + r3.z); d.w += (r0.w + r1.w) + (r2.w + r3.w);
+    stcat_st4(out + i * 4, d);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -607,7 +607,7 @@ int launch_pl_wgrad(PlParams p, int rows, int cols, int red, hipStream_t st, flo
     if (int rc = launch_status()) return rc;
     if (!use_ws) return 0;
     const long n4 = out_floats / 4;
-    STCAT_LAUNCH(pl_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, p.Wf, n4,
+    STCAT_LAUNCH(pl_wgrad_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, (const float*)ws, p.Wf, n4,
                  nsplit, out_floats);
     return launch_status();
   };
