@@ -32,6 +32,8 @@ struct OptHyper {
   float bc1, bc2;      // 1 - beta^t
   float max_norm;      // <= 0: no clipping
   float ema_decay;
+  int skip_nonfinite;  // 1: a non-finite gradient norm skips the update (the fp16-plane mode's loss-scale policy); 0: the
+                       // reference's behaviour — clip_grad_norm_ multiplies by max_norm / inf = 0 and inf * 0 = NaN propagates
 };
 
 __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const OptTensor* tab, const int* chunk_tensor,
@@ -80,10 +82,11 @@ __global__ void __launch_bounds__(256) adamw_ema_kernel(const OptTensor* tab, co
   float coef = 1.f;
   if (h.max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
     const float sq = *sqnorm;
-    // A non-finite global gradient norm (an overflow: fp16 planes with too large a loss scale, a diverged step) SKIPS the
-    // whole update, as torch.cuda.amp.GradScaler.step does — clipping alone would turn inf * 0 into NaN weights.  The
-    // caller sees it in the squared norm AdamW.step() returns (optim.PlaneLossScale reads it).
-    if (!(sq <= 3.0e38f)) return;
+    // Mode f16x3p only (skip_nonfinite): a non-finite global gradient norm (an overflow: fp16 planes with too large a loss
+    // scale) SKIPS the whole update, as torch.cuda.amp.GradScaler.step does — clipping alone would turn inf * 0 into NaN
+    // weights.  The caller sees it in the squared norm AdamW.step() returns (optim.PlaneLossScale reads it).  Every other
+    // mode does what the reference does: the NaN propagates.
+    if (h.skip_nonfinite && !(sq <= 3.0e38f)) return;
     coef = h.max_norm / (sqrtf(sq) + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
   }

@@ -1346,6 +1346,7 @@ int stcat_adamw_ema_step(const void* table, const int* chunk_tensor, const long*
   h.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   h.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   h.max_norm = max_norm; h.ema_decay = ema_decay;
+  h.skip_nonfinite = g_pl_f16 ? 1 : 0;
   STCAT_LAUNCH(adamw_ema_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table,
                chunk_tensor, chunk_off, chunk, sqnorm, h);
   return launch_status();

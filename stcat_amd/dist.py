@@ -148,6 +148,8 @@ class GradBucketReducer:
             for (n, p), v in zip(b["params"], b["views"]):
                 self._view_of[p] = v
         self._early = set()
+        self._early_stream = {}      # parameter -> the stream early() wrote its bucket view on
+        self._early_added = {}       # parameter -> (id, version) of the autograd gradient already added into its view
         if self.comm:
             from . import ops
             ops.GRAD_SINK = self   # nodes that produce many parameter gradients hand them over as they complete
@@ -161,6 +163,8 @@ class GradBucketReducer:
         for p in self.params:
             p.grad = None
         self._early.clear()
+        self._early_stream.clear()
+        self._early_added.clear()
         self._extra_work = None
         for b in self.buckets:
             b["pending"] = len(b["params"])
@@ -215,6 +219,8 @@ class GradBucketReducer:
                 srcs.append(g)
                 dsts.append(self._view_of[p])
             self._early.add(p)
+            if g.is_cuda:
+                self._early_stream[p] = torch.cuda.current_stream(g.device)
             b["pending"] -= 1
             if b["pending"] == 0:
                 touched.append(b)
@@ -283,6 +289,17 @@ class GradBucketReducer:
                 if self.buckets[self._owner[p]]["pending"] < 0:
                     raise RuntimeError("GradBucketReducer: a parameter delivered through early() received a further "
                                        "gradient from autograd after its bucket was all-reduced")
+                #  the hook fires once per accumulation with the WHOLE p.grad: a second firing on the same
+                # tensor would add the first contribution again — refuse rather than double-count
+                seen = self._early_added.get(p)
+                if seen is not None:
+                    raise RuntimeError("GradBucketReducer: a parameter delivered through early() was accumulated by autograd "
+                                       "twice in one step; run this model with STCAT_REDUCER_NO_OVERLAP=1")
+                self._early_added[p] = (id(g), g._version)
+                # early() wrote the bucket view on ITS stream (the weight-gradient stream): order this add behind it
+                st = self._early_stream.get(p)
+                if st is not None and v.is_cuda:
+                    torch.cuda.current_stream(v.device).wait_stream(st)
                 v.add_(g)
             return
         b = self.buckets[self._owner[p]]

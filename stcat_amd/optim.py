@@ -306,6 +306,18 @@ def update_ema(model, model_ema, decay: float) -> None:
 
 
 
+def set_f16_scales(weight_log2: int, grad_log2: int) -> None:
+    """the only supported way to change mode f16x3p's operand scales: a new WEIGHT scale makes every cached weight plane
+    stale (they hold w * 2^old), so the weight-plane caches are forced to refresh (ops.WEIGHT_EPOCH) and every launch plan
+    is dropped (the caches are keyed on pointers + mode, not on the scales)"""
+    from . import ops, plans
+    old_w = L.load().stcat_get_f16_scale(0)
+    L.call("stcat_set_f16_scales", int(weight_log2), int(grad_log2))
+    if int(weight_log2) != int(old_w):
+        ops.WEIGHT_EPOCH += 1
+    plans.invalidate()
+
+
 class PlaneLossScale:
     """Dynamic gradient (loss) scale of the experimental mma mode `f16x3p` — torch.cuda.amp.GradScaler's policy on the one
     number that mode needs: every GRADIENT plane of the backbone holds dy * 2^log2 (fp16's range; csrc/igemm_pl.h), the
@@ -328,8 +340,7 @@ class PlaneLossScale:
     def _apply(self):
         from . import plans
         wlog = L.load().stcat_get_f16_scale(0)
-        L.call("stcat_set_f16_scales", int(wlog), int(self.log2))
-        plans.invalidate()
+        set_f16_scales(int(wlog), int(self.log2))
 
     def update(self, sqnorm) -> bool:
         """sqnorm: what AdamW.step() returned.  -> True when the step was applied (finite norm)"""
