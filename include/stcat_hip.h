@@ -140,6 +140,9 @@ int stcat_pl_linear_fwd(const void* xh, const void* xl, const void* wh, const vo
  * forward's ymask, mask_scale = 1/(1-p). */
 int stcat_pl_linear_dgrad_mask(const void* gh, const void* gl, const void* th, const void* tl, const unsigned char* ybits,
                                const float* mask_scale, float* dxf, void* dxh, void* dxl, int M, int N, int K, void* stream);
+/* planes (h, l) of x + y and, when `sum` is given, the fp32 sum: q = k = src + pos (modal_encoder.py:234) entering the
+ * in-projection on the plane kernels in one pass; n a multiple of 8, all pointers 16-byte aligned */
+int stcat_pl_split_sum(const float* x, const float* y, float* sum, void* h, void* l, long n, void* stream);
 /* out [N] (caller-zeroed) += column sums of a plane set [M][N]: the bias gradient where the upstream gradient is planes */
 int stcat_pl_colsum(const void* h, const void* l, float* out, int M, int N, void* stream);
 /* dw (fp32 OHWI, caller-zeroed) += row_scale[co] * sum over pixels g (x) gathered x; Cout % 128 == 0, Cin % 128 == 0.

@@ -75,6 +75,7 @@ SIGNATURES: Dict[str, str] = {
     "stcat_pl_linear_fwd": "ppppp" + "p" + "ppp" + "p" + "iiii" + "fllp" + "s",
     "stcat_pl_linear_dgrad_mask": "pppp" + "pp" + "ppp" + "iii" + "s",
     "stcat_pl_colsum": "pppiis",
+    "stcat_pl_split_sum": "ppppp" + "l" + "s",
     "stcat_pl_conv_dgrad_cadd": "pppppp" + "i" + "pppp" + "iiiii" + "s",
     "stcat_pl_conv_wgrad": "pppppp" + "iiiiiiiii" + "s",
     "stcat_pl_conv_wgrad_ws": "pppppp" + "iiiiiiiii" + "pl" + "s",

@@ -275,7 +275,8 @@ FUSE_FFN = not os.environ.get("STCAT_NO_FFN_FUSE")
 
 
 FFN_PLANES = not os.environ.get("STCAT_NO_FFN_PLANES")
-FFN_PLANES_FULL = not os.environ.get("STCAT_NO_FFN_PLANES_FULL")    # (linear2 and both weight gradients on the plane kernels too)
+FFN_PLANES_FULL = not os.environ.get("STCAT_NO_FFN_PLANES_FULL")
+QK_PLANES = not os.environ.get("STCAT_NO_QK_PLANES")    # (the spatial layers' q / k in-projection on the A-stationary kernel)    # (linear2 and both weight gradients on the plane kernels too)
 
 
 class FfnPlanes:
@@ -287,15 +288,21 @@ class FfnPlanes:
         self.wp = ops.WeightPlanes()
         self.gain = {}
 
-    def refresh(self, pairs, need_bwd: bool):
-        """pairs: [(W1 [F, D], W2 [D, F]), ...] -> {W1.data_ptr(): (planes of W1, of W1^T, of W2, of W2^T)}"""
+    def refresh(self, pairs, need_bwd: bool, extra=()):
+        """pairs: [(W1 [F, D], W2 [D, F]), ...] -> {W1.data_ptr(): (planes of W1, of W1^T, of W2, of W2^T)};
+        extra: further [N, K] weights (the q / k rows of the in-projections) -> their forward planes under their data_ptr"""
         ws = []
         for W1, W2 in pairs:
             ws.append(W1.view(W1.shape[0], 1, 1, W1.shape[1]))
             ws.append(W2.view(W2.shape[0], 1, 1, W2.shape[1]))
+        for W in extra:
+            ws.append(W.view(W.shape[0], 1, 1, W.shape[1]))
         fwd, tr = self.wp.refresh(ws, transposed=need_bwd)
-        return {W1.data_ptr(): (fwd[W1.data_ptr()], tr.get(W1.data_ptr()) if need_bwd else None, fwd[W2.data_ptr()],
-                                tr.get(W2.data_ptr()) if need_bwd else None) for W1, W2 in pairs}
+        out = {W1.data_ptr(): (fwd[W1.data_ptr()], tr.get(W1.data_ptr()) if need_bwd else None, fwd[W2.data_ptr()],
+                               tr.get(W2.data_ptr()) if need_bwd else None) for W1, W2 in pairs}
+        for W in extra:
+            out[("qk", W.data_ptr())] = fwd[W.data_ptr()]
+        return out
 
     def gainvec(self, like, n: int, gain: float):
         key = (str(like.device), n, round(gain, 9))
@@ -460,8 +467,18 @@ class EncoderLayerFn(Function):
         shp = x.shape
         x = x if x.is_contiguous() else x.contiguous()
         pos_b = pos if pos.shape == x.shape else pos.expand_as(x)
-        qk_in = ops.ew(L.EW_ADD, x, pos_b if pos_b.is_contiguous() else pos_b.contiguous())      # q = k = src + pos :234
-        qk, x_qk = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
+        wqk = ffn_pl[0].get(("qk", W_in.data_ptr())) if (ffn_pl is not None and QK_PLANES) else None
+        if wqk is not None:
+            # q = k = src + pos as planes in ONE pass, the [M, 2D] in-projection on the A-stationary plane kernel (round 5)
+            qk_in, qkp = ops.pl_split_sum(x, pos_b if pos_b.is_contiguous() else pos_b.contiguous())
+            M_ = qk_in.numel() // D
+            qk = torch.empty(*shp[:-1], 2 * D, device=x.device, dtype=torch.float32)
+            L.call("stcat_pl_linear_fwd", qkp.h, qkp.l, wqk.h, wqk.l, B_in[:2 * D].data_ptr(), None, qk.data_ptr(), None, None,
+                   None, M_, 2 * D, D, 0, 0.0, 0, 0, None, L.stream_of(x))
+            x_qk = qk_in.view(M_, D)
+        else:
+            qk_in = ops.ew(L.EW_ADD, x, pos_b if pos_b.is_contiguous() else pos_b.contiguous())      # q = k = src + pos :234
+            qk, x_qk = _lin_f(qk_in, W_in[:2 * D], B_in[:2 * D])
         v, x_v = _lin_f(x, W_in[2 * D:], B_in[2 * D:])
         (a, _), c_att = _f(ops.MhaSelfFn, (True, False, True) + (False,) * 5, qk, qk[:, :, D:], v, kpm,
                            (D // nhead) ** -0.5, False, True, p)
@@ -1006,7 +1023,8 @@ class EncoderFn(Function):
             # the spatial layers' FFN (13 248 x 256 -> 2048 at C3) on the plane kernels: ONE refresh of their weight planes
             pairs = [(prm[(2 * i) * _NE_LAYER + 6], prm[(2 * i) * _NE_LAYER + 8]) for i in range(nl)]
             need_bwd = any(w.requires_grad for pr in pairs for w in pr)
-            ffn_pl = (wpc.refresh(pairs, need_bwd), wpc)
+            wqks = [prm[(2 * i) * _NE_LAYER][:2 * d] for i in range(nl)] if QK_PLANES else []     # q / k rows of W_in
+            ffn_pl = (wpc.refresh(pairs, need_bwd, extra=wqks), wpc)
         for i in range(nl):
             sp = prm[(2 * i) * _NE_LAYER:(2 * i + 1) * _NE_LAYER]
             tp = prm[(2 * i + 1) * _NE_LAYER:(2 * i + 2) * _NE_LAYER]

@@ -899,9 +899,17 @@ struct PlEwParams {
 __global__ void __launch_bounds__(256) planes_ew_kernel(PlEwParams p) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n8; i += (long)gridDim.x * blockDim.x) {
     float v[8];
-    if (p.mode == 0 || p.mode == 1) {
+    if (p.mode == 0 || p.mode == 1 || p.mode == 4) {
       const float4 a = stcat_ld4(p.xf + i * 8), b = stcat_ld4(p.xf + i * 8 + 4);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+      if (p.mode == 4) {        // split of a SUM (q = k = src + pos, modal_encoder.py:234): the fp32 sum is kept for the weight gradient
+        const float4 c = stcat_ld4(p.yf + i * 8), d = stcat_ld4(p.yf + i * 8 + 4);
+        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w; v[4] += d.x; v[5] += d.y; v[6] += d.z; v[7] += d.w;
+        if (p.of) {
+          stcat_st4(p.of + i * 8, make_float4(v[0], v[1], v[2], v[3]));
+          stcat_st4(p.of + i * 8 + 4, make_float4(v[4], v[5], v[6], v[7]));
+        }
+      }
     } else {
       stcat_load_planes(p.Xh, p.Xl, i * 8, p.np, v);
     }

@@ -1571,6 +1571,15 @@ int stcat_pl_split(const float* x, void* h, void* l, long n, void* stream) {
   return pl_ew(p, n, stream);
 }
 
+// planes of x + y, and (optional) the fp32 sum itself: the encoder's q = k = src + pos feeding the in-projection on the
+// plane kernels without a separate add pass (round 5)
+int stcat_pl_split_sum(const float* x, const float* y, float* sum, void* h, void* l, long n, void* stream) {
+  if (!x || !y || !h || !l) return fail("pl_split_sum: x, y and the plane pair are required");
+  PlEwParams p = {};
+  p.mode = 4; p.xf = x; p.yf = y; p.of = sum; p.Rh = (__bf16*)h; p.Rl = (__bf16*)l; p.C = 8;
+  return pl_ew(p, n, stream);
+}
+
 int stcat_pl_join(const void* h, const void* l, float* out, long n, void* stream) {
   PlEwParams p = {};
   p.mode = 3; p.Xh = (const __bf16*)h; p.Xl = (const __bf16*)l; p.of = out; p.C = 8;
@@ -1759,6 +1768,7 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_pl_linear_fwd),
     STCAT_PLAN_FN(stcat_pl_linear_dgrad_mask),
     STCAT_PLAN_FN(stcat_pl_colsum),
+    STCAT_PLAN_FN(stcat_pl_split_sum),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad),
     STCAT_PLAN_FN(stcat_pl_conv_wgrad_ws),
     STCAT_PLAN_FN(stcat_pl_maxpool3x3s2),

@@ -1405,6 +1405,17 @@ def pl_split(x: torch.Tensor) -> Planes:
     return out
 
 
+def pl_split_sum(x: torch.Tensor, y: torch.Tensor, want_sum: bool = True):
+    """(x + y as fp32 | None, planes of x + y) in one pass"""
+    x, y = _c(x), _c(y)
+    _chk(x, y)
+    assert x.shape == y.shape
+    out = Planes.empty(x, *x.shape)
+    sm = torch.empty_like(x) if want_sum else None
+    L.call("stcat_pl_split_sum", x.data_ptr(), y.data_ptr(), L._ptr(sm), out.h, out.l, x.numel(), L.stream_of(x))
+    return sm, out
+
+
 def pl_join(p: Planes) -> torch.Tensor:
     out = torch.empty(p.shape, device=p.device, dtype=_f32)
     L.call("stcat_pl_join", p.h, p.l, out.data_ptr(), p.numel(), L.stream_of(out))

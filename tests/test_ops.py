@@ -414,6 +414,9 @@ def _pl_linear_ffn(dev, big):
             b2 = rnd(K, seed=7).to(dev)
             fwd, tr = ops.WeightPlanes().refresh([w1.view(N, 1, 1, K), w2.view(K, 1, 1, N)], transposed=True)
             w1p, w2t = fwd[w1.data_ptr()], tr[w2.data_ptr()]
+            xa = rnd(M, K, seed=11).to(dev)                               # planes of a SUM in one pass (q = k = src + pos)
+            sm, smp = ops.pl_split_sum(x, xa)
+            assert torch.equal(sm, x + xa) and torch.equal(ops.pl_join(smp), sm), "pl_split_sum"
             xp = ops.pl_split(x)
             y = torch.empty(M, N, device=dev)
             bits = torch.empty(M, N // 8, device=dev, dtype=torch.uint8)
