@@ -75,7 +75,15 @@ def main():
             marks["last mha_self_bwd"] = e
         if ("igemm_pl_wgrad" in n or "igemm_bs_wgrad_kernel<256" in n) and marks["first igemm_pl_wgrad"] is None:
             marks["first igemm_pl_wgrad"] = s
+    # (round 5: the encoder FFN's weight gradients run on the plane weight-gradient kernel too, INSIDE the grounding section —
+    # the section ends at the first plane weight gradient BEHIND the last self-attention backward: the backbone's)
+    last_mha = marks["last mha_self_bwd"]
+    bb = next((s for s, e, n in step if "igemm_pl_wgrad" in n and last_mha is not None and s >= last_mha), None)
+    marks["first backbone igemm_pl_wgrad"] = bb
     print("  landmarks (ms from step start): " + ", ".join(f"{k} {((v - t0)/1e6):.2f}" for k, v in marks.items() if v))
+    if marks["first mha_self_fwd"] and bb:
+        print(f"  grounding window (first mha_self_fwd .. first backbone weight gradient): {(bb - marks['first mha_self_fwd'])/1e6:.2f} ms"
+              " (traced: the tracer serialises the streams' small launches; tools/node_times.py gives the untraced figure)")
     agg = {}
     for s, e, n in step:
         k = n.split("(")[0][:60]

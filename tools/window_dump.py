@@ -37,7 +37,10 @@ def main():
         i0, i1 = 0, len(step)
     else:
         i0 = next(i for i, r in enumerate(step) if a_from in r[2])
-        i1 = next(i for i, r in enumerate(step) if a_to in r[2] and i > i0)
+        # (the window ends at the first `--to` kernel BEHIND the last self-attention backward: since round 5 the encoder FFN's
+        #  weight gradients are igemm_pl_wgrad launches inside the grounding section)
+        last_mha = max((i for i, r in enumerate(step) if "mha_self_bwd" in r[2]), default=i0)
+        i1 = next(i for i, r in enumerate(step) if a_to in r[2] and i > max(i0, last_mha if a_to == "igemm_pl_wgrad" else i0))
     t0 = step[i0][0]
     t_end = step[i1 - 1][1] if i1 <= len(step) - 1 else step[-1][1]
     win = [r for r in step if r[0] >= t0 and r[0] < step[min(i1, len(step) - 1)][0]]
