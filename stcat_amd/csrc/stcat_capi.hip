@@ -12,6 +12,7 @@
 #include "igemm_bs.h"
 #include "igemm_pl.h"
 #include "igemm_pl_as.h"
+#include "stem_pl.h"
 #include "pointwise.h"
 #include "loss.h"
 
@@ -643,6 +644,24 @@ IgemmGeom conv_geom_fwd(int H, int W, int C, int ld, int OH, int OW, int KH, int
 }
 }  // namespace
 
+int g_stem_pl = 1;    // stcat_debug_pl_flags bit 0x8000 clear: the six-product modes run the LDS-staged bf16 stem (stem_pl.h)
+// the stem of the six-product modes (3: bf16x6, 5: bf16x6p): persistent workgroups, one per CU, over 16 x 16 output tiles
+template <bool U8>
+static int launch_stem_pl(const void* frames, const float* w, const float* in_scale, const float* in_shift, const float* scale,
+                          const float* bias, float* y, int n, int H, int W, int OH, int OW, hipStream_t st) {
+  constexpr int lds = 3 * 37 * 48 * 4 + 3 * 64 * 184 * 2;
+  if (int rc = pl_prepare(stem_pl_kernel<U8>, lds)) return rc;
+  StemPlParams q = {};
+  q.A = frames; q.w = w; q.scale = scale; q.bias = bias; q.in_scale = in_scale; q.in_shift = in_shift; q.y = y;
+  q.n = n; q.H = H; q.W = W; q.OH = OH; q.OW = OW;
+  q.tiles_x = cdiv(OW, 16); q.tiles_y = cdiv(OH, 16); q.total = n * q.tiles_x * q.tiles_y;
+  const int slots = wg_slots_as() / 2;      // one 8-wave workgroup per CU
+  STCAT_LAUNCH(stem_pl_kernel<U8>, dim3(q.total < slots ? q.total : slots), dim3(512), lds, st, q);
+  return launch_status();
+}
+static bool stem_pl_mode() { return g_stem_pl && (g_mma_mode_raw == 3 || g_mma_mode_raw == 5); }
+
+
 extern "C" {
 
 int stcat_version(void) { return 100; }
@@ -706,6 +725,8 @@ int stcat_stem_fwd(const float* frames, const float* w, const float* scale, cons
                    int H, int W, void* stream) {
   if (n <= 0 || H < 7 || W < 7) return fail("stem_fwd: bad shape n=%d H=%d W=%d", n, H, W);
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  if (stem_pl_mode())
+    return launch_stem_pl<false>(frames, w, nullptr, nullptr, scale, bias, y, n, H, W, OH, OW, (hipStream_t)stream);
   IgemmParams p = {};
   p.A = frames; p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = nullptr;
   p.M = n * OH * OW; p.N = 64; p.K = 147; p.ldb = 147; p.ldc = 64; p.ldr = 0;
@@ -720,6 +741,8 @@ int stcat_stem_u8_fwd(const unsigned char* frames_hwc, const float* w, const flo
   if (n <= 0 || H < 7 || W < 7) return fail("stem_u8_fwd: bad shape n=%d H=%d W=%d", n, H, W);
   if (!in_scale || !in_shift) return fail("stem_u8_fwd: the per-channel input scale / shift are required");
   const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+  if (stem_pl_mode())
+    return launch_stem_pl<true>(frames_hwc, w, in_scale, in_shift, scale, bias, y, n, H, W, OH, OW, (hipStream_t)stream);
   IgemmParams p = {};
   p.A = reinterpret_cast<const float*>(frames_hwc); p.B = w; p.C = y; p.scale = scale; p.bias = bias; p.res = nullptr;
   p.mscale = in_scale; p.c2scale = in_shift;
@@ -1383,6 +1406,7 @@ int stcat_debug_force_pl_tile(int index) {
 }
 
 int stcat_debug_pl_flags(int flags) {
+  g_stem_pl = (flags & 0x8000) ? 0 : 1;   // bit 0x8000: the six-product modes back on the exact-fp32 stem (A/B of stem_pl.h)
   g_pl_as_skew = (flags & 0x2000) ? ((flags >> 16) & 0xffff) : 0;
   if (flags & 0x2000) flags &= 0x1fff;
   g_pl_debug = flags & ~(4 | 128);     // bits 0,1,3.. : timing experiments (PlParams::debug, stagger)

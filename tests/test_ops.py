@@ -499,10 +499,16 @@ def _stem_uint8_loader(dev, big):
     w = rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5)
     scale, bias = rnd(64, seed=3).abs() + 0.5, rnd(64, seed=4)
     ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
-    y8 = ops.stem_u8_fwd_raw(u8.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
-    yf = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
-    close(y8.permute(0, 3, 1, 2), ref, TOL, "uint8 stem vs conv2d of the normalised tensor")
-    close(y8, yf, 2e-5, "uint8 stem vs fp32 stem")
+    old_mode = L.get_mma_mode()
+    try:
+        for mode in (old_mode, "bf16x6p"):      # (bf16x6p: the LDS-staged six-product stem, csrc/stem_pl.h)
+            L.set_mma_mode(mode)
+            y8 = ops.stem_u8_fwd_raw(u8.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+            yf = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+            close(y8.permute(0, 3, 1, 2), ref, TOL if mode != "bf16x6p" else 2e-5, f"uint8 stem vs conv2d of the normalised tensor ({mode})")
+            close(y8, yf, 2e-5, f"uint8 stem vs fp32 stem ({mode})")
+    finally:
+        L.set_mma_mode(old_mode)
 
 
 @both
@@ -512,6 +518,19 @@ def _stem_pool(dev, big):
     w = rnd(64, 3, 7, 7, seed=2, scale=147 ** -0.5)
     scale, bias = rnd(64, seed=3).abs() + 0.5, rnd(64, seed=4)
     ref = F.relu(F.conv2d(x, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    old_mode = L.get_mma_mode()
+    try:
+        # the six-product stem (csrc/stem_pl.h: 16 x 16 output tiles, LDS-staged patch) on a square clip and on a non-square
+        # one whose output (13 x 19) is not a multiple of the tile: fp32-class agreement with conv2d
+        L.set_mma_mode("bf16x6p")
+        y6 = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+        close(y6.permute(0, 3, 1, 2), ref, 2e-5, "six-product stem")
+        xn = rnd(3, 3, 26, 38, seed=12) if not big else rnd(2, 3, 405, 720, seed=12)
+        refn = F.relu(F.conv2d(xn, w, stride=2, padding=3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+        yn = ops.stem_fwd_raw(xn.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
+        close(yn.permute(0, 3, 1, 2), refn, 2e-5, "six-product stem, non-square")
+    finally:
+        L.set_mma_mode(old_mode)
     y = ops.stem_fwd_raw(x.to(dev), w.to(dev), scale.to(dev), bias.to(dev))
     close(y.permute(0, 3, 1, 2), ref, TOL, "stem")
     p = ops.maxpool_raw(y)
