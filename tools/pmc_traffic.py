@@ -34,5 +34,5 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 1))[0]
     out[name] = {"launches": fn, "read_MB_per_launch": round(2 * fs * 1024 / max(fn, 1) / 1e6, 3),
                  "write_MB_per_launch": round(ws * 1024 / max(wn, 1) / 1e6, 3)}
 from bench import source_sha  # noqa: E402
-steps = sum(v["launches"] for k, v in out.items() if "igemm_stem_kernel" in k)     # one stem launch per forward pass
+steps = sum(v["launches"] for k, v in out.items() if "igemm_stem_kernel" in k or "stem_pl_kernel" in k)     # one stem launch per forward pass
 print(json.dumps({"source_sha": source_sha(), "steps_traced": steps, "note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; per launch", "kernels": out}))

@@ -21,7 +21,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
     # steps are delimited by the frame-stack stem kernel (one per forward)
-    stems = [i for i, r in enumerate(rows) if "igemm_stem_kernel" in r[2]]
+    stems = [i for i, r in enumerate(rows) if "igemm_stem_kernel" in r[2] or "stem_pl_kernel" in r[2]]
     if len(stems) < 2:
         print("need >= 2 steps in the trace")
         return

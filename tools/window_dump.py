@@ -30,7 +30,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"),
                          r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?"))))
     rows.sort()
-    stems = [i for i, r in enumerate(rows) if "igemm_stem_kernel" in r[2]]
+    stems = [i for i, r in enumerate(rows) if "igemm_stem_kernel" in r[2] or "stem_pl_kernel" in r[2]]
     a, b = stems[-2], stems[-1]
     step = rows[a:b]
     if "--all" in sys.argv:
