@@ -295,6 +295,16 @@ int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const flo
                        const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
                        int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
                        float drop_p, long drop_seed, long drop_offset, const long* drop_base, void* stream);
+/* The recomputing pair (modal_encoder.py:236, query_decoder.py:341 — nn.MultiheadAttention's core when nobody reads the
+ * head-mean weights): the forward keeps lse [B][H][Sp][2] = (row maximum, 1 / row sum), Sp = S rounded up to 32, instead of
+ * the S x S probabilities; the backward rebuilds its probability tiles from q, k and lse.  S <= 256; kpm / drop_* as above. */
+int stcat_mha_self_fwd_lse(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
+                           int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p,
+                           long drop_seed, long drop_offset, const long* drop_base, void* stream);
+int stcat_mha_self_bwd_lse(const float* q, const float* k, const float* v, const unsigned char* kpm, const float* out,
+                           const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int H, int S,
+                           int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, float drop_p,
+                           long drop_seed, long drop_offset, const long* drop_base, void* stream);
 /* The same core on the bf16 matrix pipe (split-bf16 x3 products, fp32 accumulate) with an online softmax: any S,
  * nothing but the row log-sum-exp lse[B,H,S] kept for backward (no probability stash); no head-mean weights.
  * stcat_mha_bs_bwd recomputes the probabilities from q, k and lse and produces dq, dk, dv in ONE launch (S <= 256).

@@ -54,6 +54,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_dropout": "ppplfllps",
     "stcat_mha_self_fwd": "ppppppiiiiiiif" + "fllps",
     "stcat_mha_self_bwd": "pppppppppppp" + "iiiiiiiiif" + "fllps",
+    "stcat_mha_self_fwd_lse": "pppppp" + "iiiiiiif" + "fllps",
+    "stcat_mha_self_bwd_lse": "pppppppppp" + "iiiiiiiiif" + "fllps",
     "stcat_mha_bs_fwd": "pppppp" + "iiiiiiif" + "fllps",
     "stcat_mha_bs_bwd": "pppppppppp" + "iiiiiiiiif" + "fllps",
     "stcat_attn_weights_mean": "ppiii" + "fllps",

@@ -33,6 +33,7 @@ struct AttnParams {
   float scale;
   DropParams drop;   // dropout on the probabilities (attention.py:381 / nn.MultiheadAttention); Pt keeps the
                      // UNdropped softmax, every consumer regenerates the mask from counter (bh*Sp + key)*Sp + query
+  float* Lse;        // [B][H][Sp][2] (row maximum, 1 / row sum) for the recomputing backward (round 5), or null
 };
 
 
@@ -104,6 +105,11 @@ __global__ void __launch_bounds__(64 * NT) mha_self_fwd_kernel(AttnParams p) {
   }
   sum += __shfl_xor(sum, 32);
   const float inv = 1.f / sum;
+  if (p.Lse && hi == 0) {    // (rows past S: finite values that make the recomputed probability zero)
+    float* l2 = p.Lse + ((long)blockIdx.x * SP + q) * 2;
+    l2[0] = q < p.S ? mx : 0.f;
+    l2[1] = q < p.S ? inv : 0.f;
+  }
   float* Ptg = p.Pt + (long)blockIdx.x * SP * SP;
   f32x16 o;
   STCAT_UNROLL
@@ -144,6 +150,8 @@ struct AttnBwdParams {
   int ldq, ldk, ldv, ldo, ldg, ldgv;  // ldg: row stride of dQ and dK, ldgv: of dV
   float scale;
   DropParams drop;
+  const float* Lse;          // recomputing form (round 5): [B][H][Sp][2] from the forward; Pt / dSt unused
+  const unsigned char* kpm;  // recomputing form: the forward's key padding mask
 };
 
 // backward, phase 1: one wave per query tile -> dS (stored key-major, pre-multiplied by scale) and dQ
@@ -277,6 +285,186 @@ __global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_kernel(AttnBwdParams
     dk = STCAT_MFMA_32x32x2(sv.z, Qs[(qb + 2) * 32 + l31], dk);
     dv = STCAT_MFMA_32x32x2(pv.w, dOs[(qb + 3) * 32 + l31], dv);
     dk = STCAT_MFMA_32x32x2(sv.w, Qs[(qb + 3) * 32 + l31], dk);
+  }
+  float* gv = p.dV + (long)b * p.S * p.ldgv + h * 32 + l31;
+  float* gk = p.dK + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (kk < p.S) {
+      gv[(long)kk * p.ldgv] = dv[r];
+      gk[(long)kk * p.ldg] = dk[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Recomputing backward (round 5): the forward keeps (row maximum, 1 / row sum) per query instead of the S x S probability
+// matrix, and both backward kernels rebuild their probability tiles with the forward's own instruction sequence
+// (K q^T on the fp32 pipe, exp(s + mask - max) / sum).  Per layer at C3 this removes the 103 MB probability stash the
+// forward wrote and the 103 + 103 MB (Pt, dSt) each backward kernel moved — 515 MB of the attention's HBM traffic — for
+// 112 (dQ) and 224 (dK / dV) more fp32 MFMAs per wave.  Used when nobody reads the head-mean weights and S <= 256.
+// ---------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) mha_self_bwd_dq_rc_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int SP = NT * 32, KLD = 33;
+  STCAT_DYN_SHARED(float, sm);
+  float* Ks = sm;                 // [SP][33]: column reads (A operand of K q^T) and row reads (B operand of dS K)
+  float* Vs = Ks + SP * KLD;      // [SP][33]: A operand of dP^T = V dO^T
+  float* kb = Vs + SP * KLD;
+  const int t = threadIdx.x, lane = t & 63, qt = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const float* Kg = p.K + (long)b * p.S * p.ldk + h * 32;
+  const float* Vg = p.V + (long)b * p.S * p.ldv + h * 32;
+  for (int i = t; i < SP * 8; i += 64 * NT) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (row < p.S) {
+      kv = stcat_ld4(Kg + (long)row * p.ldk + c4);
+      vv = stcat_ld4(Vg + (long)row * p.ldv + c4);
+    }
+    float* kd = &Ks[row * KLD + c4];
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    float* vd = &Vs[row * KLD + c4];
+    vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+  }
+  for (int i = t; i < SP; i += 64 * NT)
+    kb[i] = (i < p.S && !(p.kpm && p.kpm[(long)b * p.S + i])) ? 0.f : STCAT_NEG_INF;
+  const int q = qt * 32 + l31;
+  float qr[16], dor[16];
+  float delta = 0.f;
+  {
+    const float* Qg = p.Q + ((long)b * p.S + q) * p.ldq + h * 32 + hi * 16;
+    const float* g = p.dO + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    const float* og = p.O + ((long)b * p.S + q) * p.ldo + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = q4, o4 = q4;
+      if (q < p.S) {
+        q4 = stcat_ld4(Qg + c * 4);
+        v4 = stcat_ld4(g + c * 4);
+        o4 = stcat_ld4(og + c * 4);
+      }
+      qr[c * 4 + 0] = q4.x * p.scale; qr[c * 4 + 1] = q4.y * p.scale; qr[c * 4 + 2] = q4.z * p.scale; qr[c * 4 + 3] = q4.w * p.scale;
+      dor[c * 4 + 0] = v4.x; dor[c * 4 + 1] = v4.y; dor[c * 4 + 2] = v4.z; dor[c * 4 + 3] = v4.w;
+      delta += v4.x * o4.x + v4.y * o4.y + v4.z * o4.z + v4.w * o4.w;
+    }
+  }
+  delta += __shfl_xor(delta, 32);
+  const float* l2 = p.Lse + ((long)blockIdx.x * SP + q) * 2;
+  const float mx = l2[0], inv = l2[1];
+  __syncthreads();
+  f32x16 dq;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  STCAT_UNROLL
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x16 sc, dp;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s) {      // (two independent accumulators: the chains interleave)
+      sc = STCAT_MFMA_32x32x2(Ks[(kt * 32 + l31) * KLD + hi * 16 + s], qr[s], sc);
+      dp = STCAT_MFMA_32x32x2(Vs[(kt * 32 + l31) * KLD + hi * 16 + s], dor[s], dp);
+    }
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = __expf(sc[r] + kb[key] - mx) * inv;
+      const float dpv = dp[r] * stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      const float ds = pr * (dpv - delta) * p.scale;
+      dq = STCAT_MFMA_32x32x2(ds, Ks[key * KLD + l31], dq);
+    }
+  }
+  float* g = p.dQ + (long)b * p.S * p.ldg + h * 32 + l31;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) {
+    const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (qq < p.S) g[(long)qq * p.ldg] = dq[r];
+  }
+}
+
+// one wave per key tile: for every block of 32 queries rebuild P^T and dP^T tiles with the KEY as the lane (A = the query rows
+// of Q * scale resp. dO from LDS, B = this lane's own K resp. V row): accumulator register r of such a tile holds query
+// (r & 3) + 8 (r >> 2) + 4 hi of the block — exactly the pairing of A value and k index the next MFMA (dV += P'^T dO,
+// dK += dS^T Q) wants, so the tiles never leave the registers
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) mha_self_bwd_dkv_rc_kernel(AttnBwdParams p) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int SP = NT * 32, KLD = 33;
+  STCAT_DYN_SHARED(float, sm);
+  float* Qs = sm;                  // [SP][33], PRE-SCALED (q * scale, as the forward's query registers)
+  float* dOs = Qs + SP * KLD;      // [SP][33]
+  float* mxs = dOs + SP * KLD;     // per query: row maximum, 1 / row sum, delta = dO . O
+  float* ivs = mxs + SP;
+  float* dls = ivs + SP;
+  const int t = threadIdx.x, lane = t & 63, kt = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const float* Qg = p.Q + (long)b * p.S * p.ldq + h * 32;
+  const float* Gg = p.dO + (long)b * p.S * p.ldo + h * 32;
+  const float* Og = p.O + (long)b * p.S * p.ldo + h * 32;
+  for (int i = t; i < SP * 8; i += 64 * NT) {
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv, ov = qv;
+    if (row < p.S) {
+      qv = stcat_ld4(Qg + (long)row * p.ldq + c4);
+      gv = stcat_ld4(Gg + (long)row * p.ldo + c4);
+      ov = stcat_ld4(Og + (long)row * p.ldo + c4);
+    }
+    float* qd = &Qs[row * KLD + c4];
+    qd[0] = qv.x * p.scale; qd[1] = qv.y * p.scale; qd[2] = qv.z * p.scale; qd[3] = qv.w * p.scale;
+    float* gd = &dOs[row * KLD + c4];
+    gd[0] = gv.x; gd[1] = gv.y; gd[2] = gv.z; gd[3] = gv.w;
+    float d = gv.x * ov.x + gv.y * ov.y + gv.z * ov.z + gv.w * ov.w;     // the 8 lanes of a row sit next to each other
+    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+    if ((i & 7) == 0) dls[row] = d;
+  }
+  for (int i = t; i < SP; i += 64 * NT) {
+    const float* l2 = p.Lse + ((long)blockIdx.x * SP + i) * 2;
+    mxs[i] = l2[0];
+    ivs[i] = l2[1];
+  }
+  // this lane's key row: dims hi*16 .. hi*16+15 of K and V, and its padding bias
+  const int key = kt * 32 + l31;
+  float kr[16], vr[16];
+  {
+    const float* Kg = p.K + ((long)b * p.S + key) * p.ldk + h * 32 + hi * 16;
+    const float* Vg = p.V + ((long)b * p.S + key) * p.ldv + h * 32 + hi * 16;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+      if (key < p.S) {
+        k4 = stcat_ld4(Kg + c * 4);
+        v4 = stcat_ld4(Vg + c * 4);
+      }
+      kr[c * 4 + 0] = k4.x; kr[c * 4 + 1] = k4.y; kr[c * 4 + 2] = k4.z; kr[c * 4 + 3] = k4.w;
+      vr[c * 4 + 0] = v4.x; vr[c * 4 + 1] = v4.y; vr[c * 4 + 2] = v4.z; vr[c * 4 + 3] = v4.w;
+    }
+  }
+  const float kbv = (key < p.S && !(p.kpm && p.kpm[(long)b * p.S + key])) ? 0.f : STCAT_NEG_INF;
+  __syncthreads();
+  f32x16 dv, dk;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+  for (int qb = 0; qb < NT; ++qb) {
+    f32x16 st, dpt;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+    STCAT_UNROLL
+    for (int s = 0; s < 16; ++s) {
+      st = STCAT_MFMA_32x32x2(Qs[(qb * 32 + l31) * KLD + hi * 16 + s], kr[s], st);
+      dpt = STCAT_MFMA_32x32x2(dOs[(qb * 32 + l31) * KLD + hi * 16 + s], vr[s], dpt);
+    }
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = __expf(st[r] + kbv - mxs[q]) * ivs[q];
+      const float m = stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      const float ds = pr * (dpt[r] * m - dls[q]);           // (the scale rides in Qs: dK = dS^T (q * scale))
+      dv = STCAT_MFMA_32x32x2(pr * m, dOs[q * KLD + l31], dv);
+      dk = STCAT_MFMA_32x32x2(ds, Qs[q * KLD + l31], dk);
+    }
   }
   float* gv = p.dV + (long)b * p.S * p.ldgv + h * 32 + l31;
   float* gk = p.dK + (long)b * p.S * p.ldg + h * 32 + l31;

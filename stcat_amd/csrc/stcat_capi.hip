@@ -1265,6 +1265,43 @@ int stcat_mha_self_fwd(const float* q, const float* k, const float* v, const uns
   return launch_status();
 }
 
+// The recomputing pair (round 5): the forward keeps (row maximum, 1 / row sum) per query in lse [B][H][Sp][2] instead of the
+// S x S probabilities; the backward rebuilds its probability tiles (csrc/attention.h).  S <= 256, no head-mean weights.
+int stcat_mha_self_fwd_lse(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
+                           int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p,
+                           long drop_seed, long drop_offset, const long* drop_base, void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0 || S > 256) return fail("mha_self_fwd_lse: bad shape (S = %d, at most 256)", S);
+  if ((ldq | ldk | ldv) % 4 != 0 || !aligned16(q) || !aligned16(k) || !aligned16(v) || !lse)
+    return fail("mha_self_fwd_lse: q/k/v must be 16-byte aligned with ld %% 4 == 0, lse set");
+  AttnParams p = {q, k, v, o, nullptr, kpm, B, H, S, ldq, ldk, ldv, ldo, scale,
+                  stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base), lse};
+  const int nt = cdiv(S, 32);
+  STCAT_NT_SWITCH(nt, STCAT_LAUNCH((mha_self_fwd_kernel<NT>), dim3(B * H), dim3(64 * NT), 0, (hipStream_t)stream, p))
+  return launch_status();
+}
+
+int stcat_mha_self_bwd_lse(const float* q, const float* k, const float* v, const unsigned char* kpm, const float* out,
+                           const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int H, int S,
+                           int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, float drop_p,
+                           long drop_seed, long drop_offset, const long* drop_base, void* stream) {
+  if (S <= 0 || B <= 0 || H <= 0 || S > 256) return fail("mha_self_bwd_lse: bad shape (S = %d, at most 256)", S);
+  if ((ldq | ldk | ldv | ldo) % 4 != 0 || !lse) return fail("mha_self_bwd_lse: ld %% 4 != 0 or lse missing");
+  AttnBwdParams p = {};
+  p.Q = q; p.K = k; p.V = v; p.dO = dout; p.O = out; p.Lse = lse; p.kpm = kpm;
+  p.dQ = dq; p.dK = dk; p.dV = dv; p.B = B; p.H = H; p.S = S;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldg = ldg; p.ldgv = ldgv; p.scale = scale;
+  p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
+  const int nt = cdiv(S, 32), sp = nt * 32;
+  const int lds_q = (2 * sp * 33 + sp) * 4, lds_kv = (2 * sp * 33 + 3 * sp) * 4;
+  STCAT_NT_SWITCH(nt, {
+    if (int rc = pl_prepare(mha_self_bwd_dq_rc_kernel<NT>, 80 * 1024)) return rc;
+    if (int rc = pl_prepare(mha_self_bwd_dkv_rc_kernel<NT>, 80 * 1024)) return rc;
+    STCAT_LAUNCH((mha_self_bwd_dq_rc_kernel<NT>), dim3(B * H), dim3(64 * NT), lds_q, (hipStream_t)stream, p);
+    STCAT_LAUNCH((mha_self_bwd_dkv_rc_kernel<NT>), dim3(B * H), dim3(64 * NT), lds_kv, (hipStream_t)stream, p);
+  })
+  return launch_status();
+}
+
 int stcat_mha_self_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                        const float* pt, const float* dw, float* corr, float* dst, float* dq, float* dk, float* dv,
                        int B, int H, int S, int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale,
@@ -1772,6 +1809,8 @@ const stcat_plan::FnEntry g_plan_fns[] = {
     STCAT_PLAN_FN(stcat_dropout),
     STCAT_PLAN_FN(stcat_mha_self_fwd),
     STCAT_PLAN_FN(stcat_mha_self_bwd),
+    STCAT_PLAN_FN(stcat_mha_self_fwd_lse),
+    STCAT_PLAN_FN(stcat_mha_self_bwd_lse),
     STCAT_PLAN_FN(stcat_mha_bs_fwd),
     STCAT_PLAN_FN(stcat_mha_bs_bwd),
     STCAT_PLAN_FN(stcat_attn_weights_mean),

@@ -889,6 +889,13 @@ def _ld3(t: torch.Tensor) -> int:
     return t.stride(1)
 
 
+# fp32-pipe self-attention: keep only (row max, 1 / row sum) and recompute the probability tiles in the backward instead of
+# stashing the S x S matrix.  OPT-IN: it removes 515 MB of HBM traffic per encoder layer but costs 336 more 64-cycle fp32
+# MFMAs per wave — measured +0.25 ms per C3 step (profiles/r05_as_kernel_experiments.log, item 8); it halves the
+# attention's activation memory, which is what it is kept for.
+MHA_RECOMPUTE = bool(os.environ.get("STCAT_MHA_RECOMPUTE"))
+
+
 class MhaSelfFn(Function):
     """softmax(scale * q k^T + key_padding) v per (batch, head), head dim 32 — the core of
     torch.nn.MultiheadAttention after its in-projection (modal_encoder.py:236; query_decoder.py:341, 604).
@@ -928,6 +935,20 @@ class MhaSelfFn(Function):
                 ctx.save_for_backward(q, k, v, o, lse, kp)
             ctx.mark_non_differentiable()
             return o, None
+        # fp32-pipe kernels.  When nobody reads the head-mean weights and a row fits the short-row kernels, the forward keeps
+        # only (row maximum, 1 / row sum) and the backward recomputes its probability tiles (round 5): no S x S stash
+        ctx.rc = (not need_weights) and S <= 256 and MHA_RECOMPUTE and any(ctx.needs_input_grad[:3])
+        if ctx.rc:
+            lse = _empty(v, B, H, SP, 2)
+            drop = (0.0, 0, 0, None)
+            if drop_p > 0.0:
+                drop = (float(drop_p),) + _dropout_stream.take(B * H * SP * SP, v.device)
+            L.call("stcat_mha_self_fwd_lse", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), lse.data_ptr(),
+                   B, H, S, _ld3(q), _ld3(k), _ld3(v), D, scale, *drop, L.stream_of(v))
+            ctx.drop = drop
+            ctx.save_for_backward(q, k, v, o, lse, kp)
+            ctx.mark_non_differentiable()
+            return o, None
         # probabilities are kept only when somebody will read them: backward, or the head-mean weights
         keep = need_weights or any(ctx.needs_input_grad[:3])
         pt = _empty(v, B, H, SP, SP) if keep else None
@@ -964,6 +985,25 @@ class MhaSelfFn(Function):
                 ldg_qk = D
             dv = _empty(v, B, S, D)
             L.call("stcat_mha_bs_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), do.data_ptr(),
+                   lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, _ld3(q), _ld3(k), _ld3(v), D,
+                   ldg_qk, D, ctx.scale, *ctx.drop, L.stream_of(v))
+            if ctx.packed_qk:
+                return dqk, None, dv, None, None, None, None, None
+            return dq, dk, dv, None, None, None, None, None
+        if getattr(ctx, "rc", False):
+            q, k, v, o, lse, kp = ctx.saved_tensors
+            B, S, D = v.shape
+            H = D // 32
+            do = _c(do)
+            if ctx.packed_qk:
+                dqk = _empty(v, B, S, 2 * D)
+                dq, dk, ldg_qk = dqk[:, :, :D], dqk[:, :, D:], 2 * D
+            else:
+                dq = _empty(v, B, S, D)
+                dk = _empty(v, B, S, D)
+                ldg_qk = D
+            dv = _empty(v, B, S, D)
+            L.call("stcat_mha_self_bwd_lse", q.data_ptr(), k.data_ptr(), v.data_ptr(), L._ptr(kp), o.data_ptr(), do.data_ptr(),
                    lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, _ld3(q), _ld3(k), _ld3(v), D,
                    ldg_qk, D, ctx.scale, *ctx.drop, L.stream_of(v))
             if ctx.packed_qk:

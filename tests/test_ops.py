@@ -621,6 +621,19 @@ def _mha_self(dev, big):
     _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)
     _mha_case(dev, 1, 8, 2, need_w=True, packed=True, masked=False)
     _mha_case(dev, 1, 65, 1, need_w=True, packed=False, masked=True)
+    # the recomputing backward (opt-in, ops.MHA_RECOMPUTE: row max / sum kept, probability tiles rebuilt): masked, ragged,
+    # unpacked, with dropout
+    ops.MHA_RECOMPUTE = True
+    try:
+        _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)
+        _mha_case(dev, 1, 65, 1, need_w=False, packed=False, masked=True)
+        _mha_dropout_case(dev, 2, 37, 2, need_w=False)
+        if big:
+            _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)
+            _mha_case(dev, 2, 256, 8, need_w=False, packed=True, masked=False)
+            _mha_dropout_case(dev, 4, 207, 8, need_w=False, pdrop=0.1)
+    finally:
+        ops.MHA_RECOMPUTE = False
     # more than 256 tokens per frame (non-square clips: 405 x 720 -> 13 x 23 + text + [CLS] = 310): the long-row kernels
     # (K / V in dynamic LDS, two-pass softmax forward), forward + backward, masked, with and without the weights
     _mha_case(dev, 1, 310, 1, need_w=False, packed=True, masked=True)
