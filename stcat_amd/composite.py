@@ -108,6 +108,8 @@ def _lin_b(g, x2, w, need_dx=True, dw=None, db=None, add=None, relu_y=None, want
             db = ops._zeros(g, N)
         _wgrad(g, x2, dw, db, M, N, K)
     else:
+        #  the 4 / 2 / 1-wide heads: this kernel has no epilogue for a fused ReLU + dropout backward
+        assert mask is None, "_lin_b: mask= needs the 64-multiple data-gradient kernels (N % 64 == 0)"
         dx_ = torch.empty(M, K, device=g.device, dtype=torch.float32) if need_dx else None
         dw_ = torch.empty(N, K, device=g.device, dtype=torch.float32)
         db_ = torch.empty(N, device=g.device, dtype=torch.float32) if want_db else None
@@ -320,7 +322,7 @@ def _ffn_f(x, W1, b1, W2, b2, g, be, p, pl=None):
     epilogue of linear2's data gradient (stcat_linear_dgrad_mask): per layer one [M, 2048] pass less forward (the dropout
     launch) and two less backward (dropout + ReLU backward) — 125 us per spatial encoder layer at C3 — and the pre-dropout
     activation is no longer kept.  The split-bf16 modes only; mma mode f32 keeps the separate launches."""
-    if FUSE_FFN and L.get_mma_mode() != "f32" and W1.shape[0] % 64 == 0:
+    if FUSE_FFN and L.get_mma_mode() != "f32" and W1.shape[0] % 64 == 0 and W2.shape[0] % 64 == 0:
         shp = x.shape
         K = shp[-1]
         x2 = x if x.dim() == 2 else x.reshape(-1, K)
@@ -707,6 +709,11 @@ class BoxDecoderFn(Function):
             lpm = prm[_N_SHARED + i * _N_LAYER + 36: _N_SHARED + (i + 1) * _N_LAYER]
             (Wmk_, bmk_, Wmp_, bmp_, Wmv_, bmv_) = lpm
             kpi_, vvi_, kci_ = (ops._empty(memory, rows, D) for _ in range(3))     # (allocated on the chain's stream)
+            # The lane is ordered behind the chain HERE, after the allocations: the caching allocator may
+            # hand back a block whose last kernel — a temporary of layer i freed on the host — is still queued on the
+            # chain's stream; an idle lane would write it first and the late chain kernel would overwrite the projection.
+            # The chain has just waited for the lane (sync_main), so this costs no overlap.
+            lane.fork()
             with lane:
                 ops.linear_fwd_raw(x_pos, Wmp_, bmp_, out=kpi_)                                # :355-358
                 ops.linear_fwd_raw(x_mem, Wmv_, bmv_, out=vvi_)
@@ -714,7 +721,6 @@ class BoxDecoderFn(Function):
             lane.keep(kpi_, vvi_, kci_)
             return (kci_.view(memory.shape), kpi_.view(memory.shape), vvi_.view(memory.shape))
 
-        lane.fork()
         nxt = mem_proj(0)
         for i in range(nl):
             lp = prm[_N_SHARED + i * _N_LAYER: _N_SHARED + (i + 1) * _N_LAYER]

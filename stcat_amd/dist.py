@@ -149,7 +149,7 @@ class GradBucketReducer:
                 self._view_of[p] = v
         self._early = set()
         self._early_stream = {}      # parameter -> the stream early() wrote its bucket view on
-        self._early_added = {}       # parameter -> (id, version) of the autograd gradient already added into its view
+        self._early_added = set()    # parameters whose autograd-accumulated gradient was already added into their view
         if self.comm:
             from . import ops
             ops.GRAD_SINK = self   # nodes that produce many parameter gradients hand them over as they complete
@@ -191,7 +191,11 @@ class GradBucketReducer:
     def early(self, params, grads) -> bool:
         """Called from INSIDE a backward node, on the stream that produced `grads`: take these parameter gradients
         now (the node then returns None for them, so no AccumulateGrad / hook runs later).  Copies run on the current
-        stream, i.e. behind the kernels that wrote the gradients; a bucket that completes is reduced right away."""
+        stream, i.e. behind the kernels that wrote the gradients; a bucket that completes is reduced right away.
+        A second early() delivery of a parameter in one step ADDS (again_s / again_d).  A parameter that is delivered
+        here AND accumulated by autograd (used outside the delivering node too) may receive exactly ONE autograd
+        contribution per step: the post-accumulate hook sees the whole p.grad each time, so a second firing cannot be
+        told from a re-delivery and _on_grad refuses it — such models need STCAT_REDUCER_NO_OVERLAP=1."""
         if not self.comm or self.deferred:
             return False
         touched = []
@@ -291,11 +295,10 @@ class GradBucketReducer:
                                        "gradient from autograd after its bucket was all-reduced")
                 #  the hook fires once per accumulation with the WHOLE p.grad: a second firing on the same
                 # tensor would add the first contribution again — refuse rather than double-count
-                seen = self._early_added.get(p)
-                if seen is not None:
+                if p in self._early_added:
                     raise RuntimeError("GradBucketReducer: a parameter delivered through early() was accumulated by autograd "
                                        "twice in one step; run this model with STCAT_REDUCER_NO_OVERLAP=1")
-                self._early_added[p] = (id(g), g._version)
+                self._early_added.add(p)
                 # early() wrote the bucket view on ITS stream (the weight-gradient stream): order this add behind it
                 st = self._early_stream.get(p)
                 if st is not None and v.is_cuda:

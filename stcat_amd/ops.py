@@ -327,8 +327,9 @@ def _pad8(xs):
 
 
 def linear_multi_ok(M: int, N: int, K: int, like: torch.Tensor) -> bool:
-    """the grouped skinny-Linear launches apply: a split-bf16 mode, M <= 128, 64-multiples, and a source of zeroed outputs"""
-    return (MULTI_LINEAR and L.get_mma_mode() != "f32" and M <= 128 and N % 64 == 0 and K % 64 == 0
+    """the grouped skinny-Linear launches apply: a split-bf16 mode, M <= 128, 128-multiples (stcat_linear_wgrad_multi's
+    tile, dense leading dimensions), and a source of zeroed outputs"""
+    return (MULTI_LINEAR and L.get_mma_mode() != "f32" and M <= 128 and N % 128 == 0 and K % 128 == 0
             and (L.RECORDER is not None or _ARENA.get(str(like.device)) is not None))
 
 
@@ -1559,12 +1560,30 @@ def _wgrad_workspace(device, stream):
     else:
         key = (str(device), int(stream) if stream is not None else 0)
     ws = _WGRAD_WS.get(key)
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if ws is None and WGRAD_WS_FLOATS > 0:
-        if L.RECORDER is not None:
-            return None
+        if L.RECORDER is not None or capturing:
+            return None       # (a recording / a hipGraph capture cannot allocate persistent memory: atomics path)
         ws = _WGRAD_WS[key] = torch.empty(WGRAD_WS_FLOATS if device.type == "cuda" else min(WGRAD_WS_FLOATS, 1 << 22),
                                           device=device, dtype=_f32)
+    rec = L.RECORDER
+    if ws is not None and rec is not None and device.type == "cuda" and rec.slots.get(key[1]) == 0:
+        #  the workspace is keyed by the stream the launch was RECORDED on, but a replay maps slot 0 to
+        # whatever stream is current then: replayed elsewhere, the plan would share this buffer with eager launches of
+        # the recorded stream, unordered.  Refuse such a replay instead of racing.
+        want = key[1]
+
+        def _same_stream(want=want, device=device):
+            if torch.cuda.current_stream(device).cuda_stream != want:
+                raise L.StcatHipError("launch plan: recorded with a weight-gradient workspace of another stream; replay "
+                                      "it on the stream it was recorded on, or call stcat_amd.plans.clear()")
+        rec.prereq(_same_stream)
     return ws
+
+
+def free_wgrad_workspaces() -> None:
+    """drop the per-stream workspaces (plans.clear(): the plans that baked their addresses are gone)"""
+    _WGRAD_WS.clear()
 
 
 def pl_act_bwd_raw(dy: torch.Tensor, y: Optional[torch.Tensor], scale, want_g=True, want_res=False, relu=True):

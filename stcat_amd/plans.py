@@ -59,6 +59,8 @@ def clear() -> None:
     for cache in _CACHES:
         cache.clear()
     invalidate()
+    from . import ops
+    ops.free_wgrad_workspaces()      # (their addresses were baked into the plans dropped above)
     # the dropped entries own torch.cuda.MemPool objects and sit in reference cycles (ctx <-> tensors): collect them NOW.
     # Left to the cyclic GC, a pool's destructor may run in the middle of a later recording — inside
     # torch.cuda.use_mem_pool — where the caching allocator aborts the process (captures_underway.empty() assert; seen in
