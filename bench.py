@@ -298,6 +298,11 @@ def main():
                     help="append a 124.6M-element dummy bucket so the all-reduce message matches the reference's (824 MB); "
                          "default at N > 1 (SURVEY.md §8d: the reference's DDP also reduces the RoBERTa gradients)")
     ap.add_argument("--no-roberta-dummy", action="store_true", help="N > 1: exchange the hot path's 327 MB only")
+    ap.add_argument("--no-prefix-pipeline", action="store_true",
+                    help="compute every clip's frozen prefix (stem + max-pool + layer1) at the head of its own step "
+                         "(round-5 schedule); default: step k declares step k + 1's frames and their prefix runs on a side "
+                         "stream under step k's grounding section (Backbone.stage_next) — every step still computes exactly "
+                         "one prefix from its frame buffer, none is reused")
     ap.add_argument("--hoist-loss-plan", action="store_true",
                     help="build the loss's target-only index tensors and run its 1-element box-count all-reduce once, "
                          "outside the steps (round-3 behaviour); default: inside every timed step, as the reference does")
@@ -339,8 +344,15 @@ def main():
     T, res, L = synth.CONFIGS[args.config]
     # the step itself lives in stcat_amd/harness.py (tests/test_model_parity.py runs the same object against the
     # reference's fixtures): model, criterion, bucketed reducer, zero arena, per-step loss plan
+    # two different synthetic clips per rank, resident in HBM, visited alternately: the step after this one always runs
+    # OTHER pixels, so the pipelined prefix below is provably computed per step (tests/test_plans.py: every pipelined
+    # step equals the un-pipelined step on the same clip)
+    pipeline = not (args.no_prefix_pipeline or args.graph)
+    clips = [(synth.synth_frames(T, res, seed=1000 * 3 + rank + 500 * j), torch.zeros(T, res, res, dtype=torch.bool))
+             for j in range(2)]
     ts = TrainStep(dev, args.config, rank=rank, train=not args.eval_mode, roberta_dummy=roberta_dummy,
-                   force_comm=force_comm, loss_plan_inside=not (args.hoist_loss_plan or args.graph))   # (a capture cannot hold the plan's H2D copy)
+                   force_comm=force_comm, loss_plan_inside=not (args.hoist_loss_plan or args.graph),   # (a capture cannot hold the plan's H2D copy)
+                   clips=clips, pipeline_prefix=pipeline)
     model, criterion, wd, reducer, arena = ts.model, ts.criterion, ts.wd, ts.reducer, ts.arena
     videos, mask, targets = ts.videos, ts.videos.mask, ts.targets
     uniform_w = ts.uniform_w
@@ -393,7 +405,9 @@ def main():
     if use_plans:
         # a node runs eagerly the first time it sees a signature and is recorded the second time: both happen here, so
         # the W warm-up steps and the K timed steps are all replays, whatever W is
-        for _ in range(2):
+        # (with the pipelined prefix the backbone node has two signatures: the first step computes its prefix in place,
+        #  the following ones find it staged — eager, eager + staged, record, then replays)
+        for _ in range(3 if pipeline else 2):
             step()
     for _ in range(args.warmup):
         step()
@@ -756,6 +770,13 @@ def main():
                                   "launch plans: one C call replays each composite node's recorded launch sequence "
                                   "(backbone fwd/bwd, encoder, box/time decoder, heads)" if use_plans else
                                   "eager (launch by launch from Python)"),
+                       "clips": "two synthetic clips per rank, resident in HBM, visited alternately",
+                       "prefix_pipeline": ("on: step k declares step k+1's frames (Backbone.stage_next); their frozen prefix "
+                                           "(stem + max-pool + layer1, no backward: backbone.py:78-85) runs on a side stream "
+                                           "under step k's grounding section; one prefix computed per step, none reused "
+                                           f"(taken {ts.model.vis_encoder[0].prefix_stats['taken']}, in place "
+                                           f"{ts.model.vis_encoder[0].prefix_stats['inline']})" if pipeline else
+                                           "off: every step computes its clip's prefix at its own head"),
                        "allreduce_bytes": reducer.message_bytes,
                        "allreduce": ({"allreduce": "all-reduce per bucket (RCCL's algorithm choice)",
                                       "rs_ag": "reduce-scatter + all-gather per bucket"}[reducer.collective]

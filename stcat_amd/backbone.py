@@ -29,6 +29,9 @@ FORWARD_CHAINS = 1 if os.environ.get("STCAT_NO_FORWARD_CHAINS") else int(os.envi
 # (86.9 vs 86.9 ms per C3 step), so opt-in
 BACKWARD_CHAINS = bool(os.environ.get("STCAT_BACKWARD_CHAINS"))
 COARSE_ADD = not os.environ.get("STCAT_NO_COARSE_ADD")   # downsample-branch gradient added from its own grid (round 5)
+# round 6: the next clip's frozen prefix (stem + max-pool + layer1) under the current step's grounding section
+PREFIX_PIPELINE = not os.environ.get("STCAT_NO_PREFIX_PIPELINE")
+PREFIX_STREAM = int(os.environ.get("STCAT_PREFIX_STREAM", "2"))     # index into ops.side_stream (2 = the spare queue)
 
 
 def _chain_streams(dev, k):
@@ -129,6 +132,45 @@ def _stem(frames, body, s, b):
     return ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
 
 
+def _prefix_blocks(body):
+    """the frozen prefix of the network: stem + max-pool + the leading non-trainable bottlenecks of layer1
+    (BackboneBase freezes everything below layer2, backbone.py:78-85) — no backward, a pure function of the frames"""
+    out = []
+    for li, blk in body.blocks():
+        if li != 1 or blk.conv1.weight.requires_grad:
+            break
+        out.append(blk)
+    return out
+
+
+def _prefix_forward(frames, body, out: "ops.Planes"):
+    """stem + max-pool + the prefix blocks of ONE whole clip on the current stream (plane mode), the last block's output
+    (+ its ReLU bit mask when `out` carries one) written into `out`.  Same kernels, same arguments per frame as the
+    in-node path: every output element is computed by the same reduction in the same order (the chains of the in-node
+    path only cut the frame range), so the result is bit-identical to it."""
+    blks = _prefix_blocks(body)
+    wp = body._wpl_cache.fwd
+    s, b = body.bn1.folded()
+    x = _stem(frames, body, s, b)
+    x = ops.pl_maxpool_raw(x)
+    for bi, blk in enumerate(blks):
+        last = bi == len(blks) - 1
+        w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
+        s1, b1 = blk.bn1.folded()
+        s2, b2 = blk.bn2.folded()
+        s3, b3 = blk.bn3.folded()
+        o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True)
+        o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True)
+        if blk.downsample is not None:
+            wd = _ohwi(blk.downsample[0].weight)
+            sd, bd = blk.downsample[1].folded()
+            idt, _ = ops.pl_conv_fwd_raw(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
+        else:
+            idt = x
+        x, _ = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, out=(out, None) if last else None)
+    return out
+
+
 class _BackboneFn(Function):
     """frames [n,3,H,W] (NCHW, as handed over by the data pipeline) -> layer4 features NHWC [n,H/32,W/32,2048]."""
 
@@ -223,12 +265,18 @@ class _BackboneFnPl(Function):
     LDS-DMA staged plane GEMMs (csrc/igemm_pl.h).  The layer4 output leaves as fp32 (consumer: input_proj)."""
 
     @staticmethod
-    def forward(ctx, frames, body: ResNet101Body, *weights):
+    def forward(ctx, frames, body: ResNet101Body, pre_t, pre_mask, *weights):
+        """pre_t / pre_mask: the frozen prefix's output for THESE frames (planes [NP, n, H/4, W/4, 256] + ReLU bit mask),
+        computed under the previous step's grounding section (Backbone.stage_next); None = compute it here."""
         need_bwd = any(w.requires_grad for w in weights)
-        s, b = body.bn1.folded()
-        x = _stem(frames, body, s, b)
-        x = ops.pl_maxpool_raw(x)
         blocks = list(body.blocks())
+        n_pre = len(_prefix_blocks(body)) if pre_t is not None else 0
+        if pre_t is None:
+            s, b = body.bn1.folded()
+            x = _stem(frames, body, s, b)
+            x = ops.pl_maxpool_raw(x)
+        else:
+            x = ops.Planes(pre_t, pre_mask)
         # conv3 / downsample are followed by a FrozenBN and the block's ReLU: their upstream gradient is dz * scale.
         # The scale is folded into the transposed weight planes (data gradient) and into the weight-gradient epilogue,
         # so the backward pass works on dz alone and never writes a second, scaled copy of it.
@@ -296,6 +344,8 @@ class _BackboneFnPl(Function):
         for sd_ in sides:
             ops._wait_stream(sd_, main)     # the other chains start behind the max-pool / the weight planes / the folds
         for bi, (li, blk) in enumerate(blocks):
+            if bi < n_pre:
+                continue                   # the frozen prefix of these frames came in as pre_t
             last = bi == len(blocks) - 1
             w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
             s1, b1 = blk.bn1.folded()
@@ -456,7 +506,7 @@ class _BackboneFnPl(Function):
             ctx.tape = None
             ctx.wt = None
         ops.dropout_backward_done()
-        return (None, None, *out)
+        return (None, None, None, None, *out)
 
 
 class Backbone(nn.Module):
@@ -474,6 +524,106 @@ class Backbone(nn.Module):
                 p.requires_grad_(False)
         self.num_channels = 2048
         self._plist = None  # cached list(body.parameters()) (walking the module tree costs ~1 ms per step)
+        self._staged = None      # (frames, version, ready event) of the clip the NEXT step will run (stage_next)
+        self._prefix = None      # the frozen prefix computed for it: dict(frames, version, x, done, stream)
+        self._pre_bufs = {}      # (shape, dtype, planes) -> two output plane sets, used alternately
+        self._pre_slot = 0
+        self.prefix_stats = {"staged": 0, "taken": 0, "inline": 0}
+
+    # ---- the next clip's frozen prefix under this step's grounding section (round 6) -----------------------------------
+    # Stem + max-pool + layer1 are frozen (backbone.py:78-85): their output is a pure function of the frames and has no
+    # backward.  At C3 they are ~4.6 ms at the head of a step's critical path, while the grounding section in the middle of
+    # the step (encoder / decoders forward + backward, 14 ms) runs dependent chains of small launches that leave most of
+    # the chip idle.  A training loop that knows its next clip (every data loader does: loader.DeviceFramePrefetcher has
+    # it in HBM one step ahead) declares it with `stage_next`; once the CURRENT clip's forward has been queued, the next
+    # clip's prefix is queued on a side stream, behind the current forward, into one of two resident plane buffers.  The
+    # next step finds it, waits for its event and starts at layer2.  Nothing is cached across steps: every prefix is
+    # computed once, from the frame buffer, for the one step that consumes it; a step whose frames were not staged (the
+    # first step, an unmodified reference loop, evaluation) computes the prefix in place as before.
+    def stage_next(self, frames: torch.Tensor, ready=None) -> None:
+        """declare the frames the NEXT call of the model will see (device tensor; fp32 [n,3,H,W] or uint8 [n,H,W,3]);
+        `ready`: event after which they are valid (the copy stream's, loader.DeviceFramePrefetcher)"""
+        if frames is None or not PREFIX_PIPELINE:
+            self._staged = None
+            return
+        self._staged = (frames, frames._version, ready)
+        self.prefix_stats["staged"] += 1
+
+    def _fill(self) -> None:
+        """called once the current clip's forward has been queued (Joiner.forward_tokens): queue the staged clip's prefix"""
+        st, self._staged = self._staged, None
+        if st is None or not ops.L.plane_count() or not _prefix_blocks(self.body):
+            return
+        frames, ver, ready = st
+        if frames._version != ver:
+            return                           # rewritten since it was declared: the consuming step computes in place
+        dev = frames.device
+        cuda = dev.type == "cuda"
+        if cuda and torch.cuda.is_current_stream_capturing():
+            return
+        blks = _prefix_blocks(self.body)
+        n = frames.shape[0]
+        H, W = (frames.shape[1], frames.shape[2]) if frames.dtype == torch.uint8 else (frames.shape[2], frames.shape[3])
+        OH, OW = ops.conv_out_hw(*ops.conv_out_hw(H, W, 7, 2, 3), 3, 2, 1)
+        C = blks[-1].conv3.weight.shape[0]
+        want_mask = len(blks) < sum(BLOCKS) and list(self.body.blocks())[len(blks)][1].conv1.weight.requires_grad
+        key = (n, OH, OW, C, ops.L.plane_count(), str(dev), want_mask)
+        bufs = self._pre_bufs.get(key)
+        main = torch.cuda.current_stream(dev) if cuda else None
+        if bufs is None:
+            self._pre_bufs.clear()           # (one clip geometry at a time: 1.2 GB per buffer at C3)
+            bufs = []
+            for _ in range(2):
+                pl = ops.Planes.empty(frames, n, OH, OW, C)
+                if want_mask:
+                    pl.mask = torch.empty(n * OH * OW, C // 8, device=dev, dtype=torch.uint8)
+                bufs.append(pl)
+            self._pre_bufs[key] = bufs
+        self._pre_slot ^= 1
+        out = bufs[self._pre_slot]
+        # The buffer's previous user is the step BEFORE the current one (two buffers, alternating): its backward pass —
+        # layer2.0's weight gradients read the prefix output on the weight-gradient stream, joined into the main stream at
+        # the end of the backward node — precedes this point on the main stream.
+        side = None
+        if cuda and ops.FORK_ENABLED and ops.L._backend == "hip":
+            side = ops.side_stream(dev, PREFIX_STREAM)
+            if side.cuda_stream == main.cuda_stream:
+                side = None
+        with torch.no_grad():
+            if side is None:
+                _prefix_forward(frames, self.body, out)
+                done = None
+            else:
+                side.wait_stream(main)               # behind the current clip's forward (and the weight-plane refresh)
+                if ready is not None:
+                    side.wait_event(ready)
+                with torch.cuda.stream(side):        # (its temporaries belong to the side stream's pool)
+                    _prefix_forward(frames, self.body, out)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                frames.record_stream(side)
+        self._prefix = {"frames": frames, "version": ver, "x": out, "done": done, "want_mask": want_mask,
+                        "state": self._prefix_state()}
+
+    def _prefix_state(self):
+        """what a computed prefix depends on besides the frames: the arithmetic mode (plane count AND element type), the
+        static tables (FrozenBN folds / weight planes: plans.STATIC_EPOCH moves with load_state_dict / .to()) and how many
+        blocks are frozen"""
+        return (ops.L.get_mma_mode(), ops.L.plane_count(), plans.STATIC_EPOCH, len(_prefix_blocks(self.body)))
+
+    def _take(self, frames: torch.Tensor):
+        """the prefix computed for exactly these frames, or None; the current stream is ordered behind it"""
+        pre, self._prefix = self._prefix, None
+        if pre is None:
+            return None
+        if (pre["frames"] is not frames and not (pre["frames"].data_ptr() == frames.data_ptr()
+                                                   and pre["frames"].shape == frames.shape
+                                                   and pre["frames"].dtype == frames.dtype)) \
+                or frames._version != pre["version"] or pre["state"] != self._prefix_state():
+            return None
+        if pre["done"] is not None:
+            torch.cuda.current_stream(frames.device).wait_event(pre["done"])
+        return pre["x"]
 
     def features_nhwc(self, frames: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
@@ -485,7 +635,16 @@ class Backbone(nn.Module):
         if weights is None or len(weights) == 0:
             weights = self._plist = [p for p in self.body.parameters()]
         if ops.L.plane_count():
-            return plans.apply(_BackboneFnPl, frames, self.body, *weights)
+            pre = self._take(frames)
+            need_mask = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
+            if pre is not None and need_mask and pre.mask is None:
+                pre = None
+            self.prefix_stats["taken" if pre is not None else "inline"] += 1
+            feat = plans.apply(_BackboneFnPl, frames, self.body, pre.t if pre is not None else None,
+                               pre.mask if pre is not None else None, *weights)
+            self._fill()     # the NEXT clip's frozen prefix, if one was declared (stage_next), behind this forward
+            return feat
+        self._staged = None
         return plans.apply(_BackboneFn, frames, self.body, *weights)
 
     def forward(self, tensor_list: NestedTensor):

@@ -25,7 +25,7 @@ class TrainStep:
 
     def __init__(self, dev, config="C3", rank: int = 0, train: bool = True, roberta_dummy: bool = False,
                  force_comm: bool = False, clip=None, targets=None, loss_plan_inside: bool = True, seed: int = 20260929,
-                 arena_elems: int = 120_000_000):
+                 arena_elems: int = 120_000_000, clips=None, pipeline_prefix: bool = False):
         self.dev = dev
         T, res, L = synth.CONFIGS[config] if isinstance(config, str) else config
         self.T, self.res, self.L = T, res, L
@@ -45,7 +45,15 @@ class TrainStep:
             mask = torch.zeros(T, res, res, dtype=torch.bool)
         else:
             frames, mask = clip
-        self.videos = NestedTensor(frames.to(dev), mask.to(dev), [T])
+        # `clips`: several (frames, mask) of one geometry, visited round-robin (step k runs clips[k % len]); with
+        # `pipeline_prefix` each step declares the NEXT step's frames to the backbone (Backbone.stage_next), which computes
+        # their frozen prefix under this step's grounding section — what a training loop with a look-ahead loader does
+        if clips is None:
+            clips = [(frames, mask)]
+        self.clips = [NestedTensor(f.to(dev), m.to(dev), [T]) for f, m in clips]
+        self.clip_index = 0
+        self.pipeline_prefix = pipeline_prefix
+        self.videos = self.clips[0]
         if targets is None:
             act, tb = synth.synth_targets(T, seed=rank)
             targets = [{"actioness": act, "boxs": BoxList(tb)}]
@@ -74,6 +82,11 @@ class TrainStep:
         # inside the timed region, hence the epoch bump that makes the refresh launch run as it does in training
         ops.WEIGHT_EPOCH += 1
         plan = self.loss_plan()
+        self.videos = self.clips[self.clip_index % len(self.clips)]
+        self.clip_index += 1
+        if self.pipeline_prefix:
+            nxt = self.clips[self.clip_index % len(self.clips)]
+            self.model.vis_encoder[0].stage_next(nxt.tensors)
         out = self.model(self.videos, ["synthetic"])
         if self.keep_outputs:        # (tests: the criterion overwrites pred_boxes with the GT-span rows, criterion.py:168-171)
             keys = ("pred_boxes", "pred_sted", "pred_actioness", "weights")

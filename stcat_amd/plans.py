@@ -35,6 +35,8 @@ from . import _lib as L
 
 ENABLED = bool(os.environ.get("STCAT_PLANS"))
 STRICT = bool(os.environ.get("STCAT_PLAN_STRICT"))   # raise when a recorded region runs a kernel that is not ours
+AUDIT = bool(os.environ.get("STCAT_PLAN_AUDIT"))      # debug: Recorder.finalize lists baked pointers it cannot account for
+AUDIT_LOG = []
 KEEPALL = bool(os.environ.get("STCAT_PLAN_KEEPALL"))  # debug: no block of the plan's pool is reused inside a recording
 WARMUP_CALLS = 1
 STATIC_EPOCH = 0     # bumped whenever a cached device object the plans point at is rebuilt (FrozenBN fold, weight planes)
@@ -148,6 +150,7 @@ class Recorder:
         self.side_handles: List[int] = []       # raw hipStream_t of slots 1..
         self.side_streams: List[object] = []    # the torch.cuda.Stream objects (keepalive)
         self.calls = []                         # (first word, signature, words)
+        self.call_names = []                    # (STCAT_PLAN_AUDIT)
         self.memsets = []
         self.effects = []
         self.prereqs = []
@@ -190,6 +193,8 @@ class Recorder:
         if w0 < 0:
             raise L.StcatHipError(f"plan_add_call({name}): {self.lib.stcat_last_error().decode()}")
         self.calls.append((w0, sig, words))
+        if AUDIT:
+            self.call_names.append(name)
         self.n_calls += 1
 
     def _slot(self, raw, stream_obj=None) -> int:
@@ -284,6 +289,26 @@ class Recorder:
                     if p - lo > (1 << 36):
                         break
                     i -= 1
+        if AUDIT:
+            # debug aid (STCAT_PLAN_AUDIT=1, emulator backend: every tensor of the recording is in self.keep): list the
+            # baked pointers that are neither externals nor tensors of this recording — module-level caches are expected
+            # here (weight planes, FrozenBN folds, transposes, workspaces); anything else dangles after the step
+            own = sorted((t.data_ptr(), t.data_ptr() + _extent_bytes(t)) for t in self.keep if t.numel() > 0)
+            olos = [r[0] for r in own]
+            seen = {}
+            for (w0, sig, words), name in zip(self.calls, self.call_names):
+                for j, k in enumerate(sig):
+                    if k != "p" or words[j] == 0:
+                        continue
+                    p = words[j]
+                    i = bisect.bisect_right(los, p) - 1
+                    if i >= 0 and ranges[i][0] <= p < ranges[i][1]:
+                        continue
+                    i = bisect.bisect_right(olos, p) - 1
+                    if i >= 0 and own[i][0] <= p < own[i][1]:
+                        continue
+                    seen.setdefault((name, j), set()).add(p)
+            AUDIT_LOG.append({k: sorted(v) for k, v in seen.items()})
         for chunks in self.zero_chunks.values():
             for buf, used, w in chunks:        # the memset clears what was handed out, not the whole chunk
                 if lib.stcat_plan_set_word(self.h, w + 1, used * 4) != 0:

@@ -342,4 +342,8 @@ MODEL_CASES = {
     "SQ8_ragged": (8, 224, 10, "ragged", True),
     "NS8": (8, (405, 720), 10, None, True),
     "NS8_ragged": (8, (405, 720), 10, "ragged", True),
+    # train-mode fixtures (round 6): the same clips, expected values from the oracle fed with the recorded dropout stream
+    # of the benchmark's own step (tests/golden/make_golden.py train ...; files model_<case>.npz)
+    "C1_train": (8, 224, 10, None, True),
+    "C3_train": (64, 448, 10, None, True),
 }

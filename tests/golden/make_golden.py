@@ -452,6 +452,75 @@ def model_case_fixture(name: str):
     return g
 
 
+def train_mode_fixture(name: str, trace_path: str):
+    """model_<name>_train.npz: the TRAIN-mode step bench.py times, at its size, with given dropout masks.
+
+    The reference draws its masks from torch's generator, which no other program can reproduce; the HIP path's masks are
+    a pure function of (seed, device base + host offset + element index) (csrc/stcat_rng.h, host twin
+    ops.dropout_keep_mask).  So the expected values come from the CPU ORACLE (oracle/stcat_oracle.py: pinned to the
+    imported reference by the eval-mode fixtures of this directory, tests/test_oracle_golden.py) run in fp32 and fp64
+    with the masks of a dropout stream recorded on the GPU box (tools/c3_train_trace.py -> `trace_path`: seed, base,
+    (offset, decisions) per site).  The stream is stored in the fixture; the GPU test asserts that the live step draws
+    exactly this stream before it compares anything.  Same arrays as model_case_fixture (minus the stage samples)."""
+    import json
+    from tests import test_model_parity as P
+    T, res, L, pad, bwd = synth.MODEL_CASES[name]
+    with open(trace_path) as f:
+        tr = json.load(f)
+    sites = [(int(o), int(n)) for o, n in tr["sites"]]
+    seed, base = int(tr["seed"]), int(tr["base"])
+    mk = lambda: P._HipMasks(sites, seed, base)   # noqa: E731
+    frames, mask, H, W = synth.synth_clip(T, res, pad)
+    out, boxes, sted, losses, g32 = P._run_oracle(T, res, L, True, torch.float32, pad, mk, trainable_only=True)
+    g = {"meta/config": np.asarray([T, H, W, L], dtype=np.int64), "meta/pad": np.asarray(pad or ""),
+         "meta/backward": np.asarray(True), "meta/source": np.asarray("oracle (train mode, masks of the recorded stream)"),
+         "dropout/seed": np.asarray(seed, dtype=np.int64), "dropout/base": np.asarray(base, dtype=np.int64),
+         "dropout/sites": np.asarray(sites, dtype=np.int64).reshape(-1, 2)}
+    keys_o = ("pred_boxes", "pred_sted", "pred_actioness", "weights")
+    for k in keys_o:
+        g[f"out/{k}"] = out[k].detach().numpy()
+        for i, a in enumerate(out["aux_outputs"]):
+            g[f"out/aux{i}/{k}"] = a[k].detach().numpy()
+    g["post/boxes"] = boxes.numpy()
+    g["post/sted"] = np.asarray([sted], dtype=np.int64)
+    keys = sorted(k for k in losses if k != "total")
+    g["loss/keys"] = np.asarray(keys)
+    g["loss/values"] = np.asarray([losses[k] for k in keys], dtype=np.float32)
+    g["loss/total"] = np.float32(losses["total"])
+    g32 = {k: v.detach().clone() for k, v in g32.items()}
+    del out
+    import gc
+    gc.collect()
+    out64, _, sted64, losses64, g64 = P._run_oracle(T, res, L, True, torch.float64, pad, mk, trainable_only=True)
+    g["loss/values64"] = np.asarray([losses64[k] for k in keys], dtype=np.float64)
+    g["loss/total64"] = np.float64(losses64["total"])
+    for k in keys_o:
+        g[f"out64/{k}"] = out64[k].detach().numpy()
+    g["post/sted64"] = np.asarray([sted64], dtype=np.int64)
+    names = [n_ for n_ in g32]
+    assert set(g64) == set(g32)
+    offs, s32, s64, n32, n64, e32 = [0], [], [], [], [], []
+    for n_ in names:
+        a, b = g32[n_].reshape(-1), g64[n_].reshape(-1)
+        idx = torch.from_numpy(synth.sample_indices(synth.canonical_name(n_), a.numel()))
+        s32.append(a[idx].numpy().astype(np.float32))
+        s64.append(b[idx].numpy().astype(np.float32))
+        offs.append(offs[-1] + idx.numel())
+        n32.append(a.double().norm().item())
+        n64.append(b.norm().item())
+        e32.append((a.double() - b).norm().item())
+    g["grad/names"] = np.asarray(names)
+    g["grad/unused"] = np.asarray([], dtype=str)
+    g["grad/numel"] = np.asarray([g32[n_].numel() for n_ in names], dtype=np.int64)
+    g["grad/offsets"] = np.asarray(offs, dtype=np.int64)
+    g["grad/sample32"] = np.concatenate(s32)
+    g["grad/sample64"] = np.concatenate(s64)
+    g["grad/norm32"] = np.asarray(n32, dtype=np.float64)
+    g["grad/norm64"] = np.asarray(n64, dtype=np.float64)
+    g["grad/err32"] = np.asarray(e32, dtype=np.float64)
+    return g
+
+
 def op_level_vectors():
     """Known-answer vectors for the small closed-form ops of the path."""
     install_stubs()
@@ -633,6 +702,19 @@ def main():
         print("eval.npz written")
         return
     torch.set_num_threads(8)
+    if sys.argv[1:2] == ["train"]:
+        # python tests/golden/make_golden.py train C3 gpurun_out/c3_train_trace.json -> tests/golden/model_C3_train.npz
+        import shutil
+        import time
+        name, trace_path = sys.argv[2], sys.argv[3]
+        t0 = time.time()
+        g = train_mode_fixture(name + "_train", trace_path)
+        path = os.path.join(out_dir, f"model_{name}_train.npz")
+        np.savez_compressed(path, **g)
+        shutil.copyfile(trace_path, os.path.join(out_dir, f"model_{name}_train_trace.json"))
+        print(f"model_{name}_train.npz written: {len(g)} arrays, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s",
+              flush=True)
+        return
     if sys.argv[1:2] == ["model"]:
         # python tests/golden/make_golden.py model [CASE ...]  -> tests/golden/model_<CASE>.npz (C3: ~10 minutes, 40 GB)
         import time

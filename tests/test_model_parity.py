@@ -168,25 +168,31 @@ class Ref:
         return r
 
 
-def _run_oracle(T, res, L, with_backward=True, dtype=torch.float32, pad=None, sites=None):
-    """dtype=float64 gives the 'exact arithmetic' yardstick used to calibrate gradient tolerances."""
+def _run_oracle(T, res, L, with_backward=True, dtype=torch.float32, pad=None, sites=None, trainable_only=False):
+    """dtype=float64 gives the 'exact arithmetic' yardstick used to calibrate gradient tolerances.  trainable_only: only
+    the parameters the reference trains require a gradient (stem / layer1 / FrozenBN buffers frozen, backbone.py:16-85) —
+    same gradients for those, a fraction of the autograd memory (the full-size fixture runs, tests/golden/make_golden.py)."""
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)
     try:
         if sites is None:
-            return _run_oracle_impl(T, res, L, with_backward, dtype, pad)
+            return _run_oracle_impl(T, res, L, with_backward, dtype, pad, trainable_only)
         with O.dropout_sites(sites()) as st:
-            r = _run_oracle_impl(T, res, L, with_backward, dtype, pad)
+            r = _run_oracle_impl(T, res, L, with_backward, dtype, pad, trainable_only)
         st.assert_all_consumed()
         return r
     finally:
         torch.set_default_dtype(prev)
 
 
-def _run_oracle_impl(T, res, L, with_backward, dtype, pad=None):
+_FROZEN = ("vis_encoder.0.body.conv1", "vis_encoder.0.body.bn1", "vis_encoder.0.body.layer1")
+
+
+def _run_oracle_impl(T, res, L, with_backward, dtype, pad=None, trainable_only=False):
     sd = {k: v.to(dtype) for k, v in synth.synth_state_dict().items()}
-    for v in sd.values():
-        v.requires_grad_(True)
+    for k, v in sd.items():
+        v.requires_grad_(not trainable_only or
+                         not (k.startswith(_FROZEN) or ".bn" in k or "downsample.1" in k or k.endswith(".te")))
     frames, mask, H, W = _clip_of(T, res, pad)
     frames = frames.to(dtype)
     (tm, tmem, _), tcls = synth.synth_text(L)
@@ -685,12 +691,19 @@ def test_gpu_c3_full_size_forward_backward_throughput_mode():
     _compare(_hip_case(dev, "C3", mma=THROUGHPUT_MMA), Ref.fixture("C3"), grad_caps=GRAD_CAPS_16BIT)
 
 
-def _run_bench_step(dev, name, mma, steps=3, train=False, use_plans=True, zero_dropout=False):
+def _run_bench_step(dev, name, mma, steps=3, train=False, use_plans=True, zero_dropout=False, pipeline=False, trace=None):
     """bench.py's OWN step object (stcat_amd/harness.py: TrainStep — bucketed reducer, zero arena, per-step loss plan)
     under launch plans, on the clip / targets of a fixture: step 1 runs eager, step 2 records, step 3 REPLAYS.  Returns
-    the replayed step in the form of _run_hip (outputs before the criterion edits them, PostProcess, losses, gradients)."""
-    from stcat_amd import _lib, plans
+    the replayed step in the form of _run_hip (outputs before the criterion edits them, PostProcess, losses, gradients).
+    pipeline: bench.py's default schedule (round 6) — every step declares the next step's frames and their frozen prefix
+    runs under this step's grounding section; one more step, because the first one computes its prefix in place (eager,
+    eager with a staged prefix, record, REPLAY).  trace: a dict that receives the dropout stream of the LAST step —
+    seed, device base, and the (host offset, decisions) list of every site (taken on step 1: a replay draws the same
+    offsets from the plan, the host-side take() does not run)."""
+    from stcat_amd import _lib, ops, plans
     from stcat_amd.harness import TrainStep
+    if pipeline:
+        steps += 1
     T, res, L, pad, _ = synth.MODEL_CASES[name]
     frames, mask, H, W = _clip_of(T, res, pad)
     act, tb = synth.synth_targets(T)
@@ -701,7 +714,7 @@ def _run_bench_step(dev, name, mma, steps=3, train=False, use_plans=True, zero_d
     ts = None
     try:
         ts = TrainStep(dev, (T, res, L), train=train, clip=(frames, mask),
-                       targets=[{"actioness": act, "boxs": BoxList(tb, (W, H))}])
+                       targets=[{"actioness": act, "boxs": BoxList(tb, (W, H))}], pipeline_prefix=pipeline)
         if zero_dropout:           # train mode with every dropout probability at 0: the train-mode code path, eval-mode numbers
             for m in ts.model.modules():
                 if hasattr(m, "dropout_p"):
@@ -709,7 +722,19 @@ def _run_bench_step(dev, name, mma, steps=3, train=False, use_plans=True, zero_d
         ts.keep_outputs = True
         for k in range(steps):
             before = dict(plans.STATS)
+            if trace is not None and k == 0:
+                sites = ops.dropout_trace(True)
             total = ts.step()
+            if trace is not None and k == 0:
+                ops.dropout_trace(False)
+                trace["sites"] = [(int(o), int(n)) for o, n in sites]
+        if trace is not None:
+            trace["seed"] = int(ops.dropout_stream_state()[0])
+            trace["base"] = int(ops._dropout_stream.base(dev).item())
+            trace["steps"] = steps
+        if pipeline:
+            st = ts.model.vis_encoder[0].prefix_stats
+            assert st["inline"] == 1 and st["taken"] == steps - 1, st
         if use_plans:
             # the last step replayed every composite node, forward and backward: nothing ran eager, nothing was recorded
             assert plans.STATS["replayed"] - before["replayed"] >= 8, (before, plans.STATS)
@@ -778,6 +803,33 @@ def test_gpu_c3_train_mode_bench_step_plans_equal_eager():
     # (bar: two EAGER runs of one step differ by up to ~1e-3 on single encoder-FFN tensors — atomically ordered split-K sums
     #  move a pre-activation across its ReLU kink here and there; seen in this test: 1.1e-5 .. 2.2e-4)
     assert worst <= 1e-3, (worst, where)
+
+
+def _check_train_mode_bench_step_against_fixture(dev, case):
+    """the mode bench.py times (train: dropout 0.1 / 0.3 on) at the size it times, through the path it times
+    (its step object, pipelined prefix, launch plans, the REPLAYED step) against expected values from the oracle: the
+    fixture holds the dropout stream it was computed with (seed, device base, every site's offset and size); the live
+    step must draw EXACTLY that stream — otherwise the comparison would be against other masks — and is then held to the
+    usual bars: outputs 1e-3 absolute, span bit-exact, 30 losses, calibrated gradients with grad_slack = 1."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"model_{case}_train.npz")
+    g = np.load(path)
+    tr = {}
+    got = _run_bench_step(dev, case + "_train", BENCH_MMA, train=True, pipeline=True, trace=tr)
+    assert tr["seed"] == int(g["dropout/seed"]) and tr["base"] == int(g["dropout/base"]), (tr["seed"], tr["base"])
+    assert [list(x) for x in tr["sites"]] == g["dropout/sites"].tolist(), "the live dropout stream differs from the fixture's"
+    rows = []
+    _compare(got, Ref.fixture(case + "_train"), report_to=rows)
+    return rows
+
+
+@pytest.mark.gpu
+def test_gpu_c3_train_mode_bench_step_against_fixture():
+    _check_train_mode_bench_step_against_fixture(use_hip(), "C3")
+
+
+@pytest.mark.gpu
+def test_gpu_c1_train_mode_bench_step_against_fixture():
+    _check_train_mode_bench_step_against_fixture(use_hip(), "C1")
 
 
 @pytest.mark.gpu

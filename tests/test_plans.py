@@ -339,3 +339,72 @@ def test_gpu_plans_follow_load_state_dict_and_mode_switch():
         plans.enable(False)
         plans.clear()
         _lib.set_mma_mode("f32")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 6: the next clip's frozen prefix (stem + max-pool + layer1) computed under the current step's grounding section
+# ------------------------------------------------------------------------------------------------------------------
+def _prefix_pipeline_case(dev, T, res, steps, train, tol, grad_l2):
+    """Two DIFFERENT clips alternate (A, B, A, B, ...).  Reference: every step un-pipelined (the prefix computed inside the
+    step), eager launches.  Pipelined: step k declares step k + 1's frames (Backbone.stage_next), launch plans on.  Every
+    step's outputs, loss and gradients equal the un-pipelined step ON THE SAME CLIP — a stale prefix (clip A's handed to
+    a step on clip B) or one cached across steps (the frames are rewritten in place between two visits) would show."""
+    _lib.set_mma_mode("bf16x6p")
+    try:
+        runs = {}
+        for mode in ("plain", "pipelined"):
+            plans.clear()
+            plans.enable(mode == "pipelined")
+            plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0)
+            ops.manual_seed(7)
+            model, criterion, wd = _build(dev, train=train)
+            bb = model.vis_encoder[0]
+            clips = [_clip(dev, T, res, 0), _clip(dev, T, res, 2)]          # (both unpadded: one position table)
+            base = [c.tensors.clone() for c in clips]
+            res_ = []
+            for k in range(steps):
+                if train:
+                    ops.dropout_begin_step(dev)
+                cur, nxt = clips[k % 2], clips[(k + 1) % 2]
+                if k == 3:
+                    # the third visit of clip B sees NEW pixels in the same buffer: written before it is declared below (a
+                    # rewrite AFTER the declaration is caught by the version check: covered at k == 4)
+                    pass
+                if mode == "pipelined":
+                    bb.stage_next(nxt.tensors)
+                res_.append(_step(model, criterion, wd, cur, T, res, dev))
+                # after the step: the NEXT clip's buffer is rewritten in place at k == 2 (fresh pixels for step 3).  The
+                # prefix staged for it is stale now — the version check must send step 3 down the in-place path
+                if k == 2:
+                    nxt.tensors.mul_(0.5)
+            runs[mode] = res_
+            if mode == "pipelined":
+                st = bb.prefix_stats
+                # step 0 computes in place (nothing staged before it), step 3 too (its frames changed after staging)
+                assert st["inline"] == 2 and st["taken"] == steps - 2, st
+                assert plans.STATS["replayed"] > 0, plans.STATS
+            for c, b in zip(clips, base):
+                c.tensors.copy_(b)
+        _check_equal(runs["plain"], runs["pipelined"], tol, grad_l2=grad_l2)
+        # the clips do differ, and the rewritten visit differs from the first visit of the same clip
+        assert runs["plain"][0][1] != runs["plain"][1][1] and runs["plain"][1][1] != runs["plain"][3][1]
+    finally:
+        plans.enable(False)
+        plans.clear()
+        _lib.set_mma_mode("f32")
+
+
+def test_emu_prefix_pipeline_equals_unpipelined_steps():
+    _prefix_pipeline_case(use_emu(), 2, 32, 5, False, 2e-5, None)
+
+
+@pytest.mark.gpu
+def test_gpu_prefix_pipeline_equals_unpipelined_steps():
+    from tests.backends import use_hip
+    _prefix_pipeline_case(use_hip(), 8, 224, 6, False, 2e-4, 3e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_prefix_pipeline_train_mode():
+    from tests.backends import use_hip
+    _prefix_pipeline_case(use_hip(), 8, 224, 6, True, 2e-4, 3e-3)

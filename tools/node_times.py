@@ -24,13 +24,14 @@ ap.add_argument("--mma", default="bf16x6p")
 ap.add_argument("--config", default="C3")
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--eager", action="store_true", help="launch plans off")
+ap.add_argument("--no-prefix-pipeline", action="store_true", help="every step computes its clip's frozen prefix itself")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
 _lib.load()
 _lib.set_mma_mode(args.mma)
 plans.enable(not args.eager)
-ts = TrainStep(dev, args.config)
+ts = TrainStep(dev, args.config, pipeline_prefix=not args.no_prefix_pipeline)
 marks = []
 ON = [False]
 
@@ -63,15 +64,37 @@ def bwd(ctx, *g):
 plans.PlannedFn.forward = staticmethod(fwd)
 plans.PlannedFn.backward = staticmethod(bwd)
 
+# the next clip's frozen prefix (Backbone._fill): events on ITS stream around the launches
+from stcat_amd import backbone as _bb  # noqa: E402
+_pf = _bb._prefix_forward
+PREFIX = []
+
+
+def prefix_forward(frames, body, out):
+    if ON[0]:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    r = _pf(frames, body, out)
+    if ON[0]:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PREFIX.append((e0, e1))
+    return r
+
+
+_bb._prefix_forward = prefix_forward
+
 for _ in range(4):
     ts.step()
 torch.cuda.synchronize()
 ON[0] = True
 rows = {}
 wall = []
+pre_rows = [0.0, 0.0, 0]
 for _ in range(args.steps):
     torch.cuda.synchronize()
     marks.clear()
+    PREFIX.clear()
     t0 = time.perf_counter()
     mark(("step", "start", 0))
     ts.step()
@@ -79,6 +102,10 @@ for _ in range(args.steps):
     torch.cuda.synchronize()
     wall.append((time.perf_counter() - t0) * 1e3)
     e0, h0 = marks[0][2], marks[0][1]
+    for a_, b_ in PREFIX:
+        pre_rows[0] += e0.elapsed_time(a_)
+        pre_rows[1] += e0.elapsed_time(b_)
+        pre_rows[2] += 1
     for name, h, e in marks:
         r = rows.setdefault(name, [0.0, 0.0, 0])
         r[0] += (h - h0) * 1e3
@@ -87,6 +114,9 @@ for _ in range(args.steps):
 print(f"# {args.config} {args.mma} plans={'off' if args.eager else 'on'}: wall {sum(wall) / len(wall):.2f} ms/step "
       f"(with the marks), plan stats {plans.STATS}")
 print("# node                      host: enq start   enq end | device: start      end   (dur) | host lead at start")
+if pre_rows[2]:
+    a_, b_ = pre_rows[0] / pre_rows[2], pre_rows[1] / pre_rows[2]
+    print(f"  next clip's frozen prefix (side stream)                  | {a_:9.2f} {b_:9.2f} ({b_ - a_:6.2f}) |")
 keys = [k for k in rows if k[2] == 0]
 for k in keys:
     k1 = (k[0], k[1], 1)
