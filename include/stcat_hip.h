@@ -49,6 +49,13 @@ int stcat_debug_streamk(int mode);
  * (HIP maps the streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues; two streams that share a queue
  * serialise, and which ones share depends on what else — RCCL, the framework — created streams before us) */
 int stcat_spin(int microseconds, void* stream);
+/* a HIP stream for a background lane of the step — round 6: the NEXT clip's frozen backbone prefix (stem + max-pool +
+ * layer1: no gradient, models/vision_model/backbone.py:78-85) runs under the current step's grounding section
+ * (stcat_amd/backbone.py: Backbone.stage_next).  priority -1 / 0 / 1 = the device's greatest / default / least stream
+ * priority; cus > 0 = a stream restricted to the first `cus` compute units (hipExtStreamCreateWithCUMask; wins over
+ * priority).  The hipStream_t comes back in *out (host pointer); the caller destroys it. */
+int stcat_stream_create(int priority, int cus, void** out);
+int stcat_stream_destroy(void* stream);
 
 /* ---- backbone: torchvision ResNet-101 + FrozenBatchNorm2d (models/vision_model/backbone.py:16-66,
  *      93-121; torch conv2d/max_pool2d underneath) ------------------------------------------------ */

@@ -93,6 +93,8 @@ SIGNATURES: Dict[str, str] = {
     "stcat_debug_force_tile": "ii",
     "stcat_debug_streamk": "i",
     "stcat_spin": "is",
+    "stcat_stream_create": "iiP",
+    "stcat_stream_destroy": "P",
     "stcat_set_mma_mode": "i",
     "stcat_get_mma_mode": "",
     "stcat_set_f16_scales": "ii",

@@ -32,6 +32,9 @@ COARSE_ADD = not os.environ.get("STCAT_NO_COARSE_ADD")   # downsample-branch gra
 # round 6: the next clip's frozen prefix (stem + max-pool + layer1) under the current step's grounding section
 PREFIX_PIPELINE = not os.environ.get("STCAT_NO_PREFIX_PIPELINE")
 PREFIX_STREAM = int(os.environ.get("STCAT_PREFIX_STREAM", "2"))     # index into ops.side_stream (2 = the spare queue)
+PREFIX_PRIO = int(os.environ.get("STCAT_PREFIX_PRIO", "0"))         # 0 = a measured-concurrent default-priority side stream; 1 = least priority
+PREFIX_CUS = int(os.environ.get("STCAT_PREFIX_CUS", "0"))           # > 0: the prefix stream is masked to this many CUs
+PREFIX_AT = os.environ.get("STCAT_PREFIX_AT", "decoder")             # "decoder": queued at the query decoder's entry; "backbone"
 
 
 def _chain_streams(dev, k):
@@ -130,6 +133,34 @@ def _stem(frames, body, s, b):
     if frames.dtype == torch.uint8:
         return ops.stem_u8_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
     return ops.stem_fwd_raw(frames.contiguous(), body.conv1.weight.contiguous(), s, b)
+
+
+_PREFIX_LANES = {}
+
+
+def _prefix_lane(dev):
+    """the stream the next clip's prefix runs on.  Default: the spare one of the package's measured-concurrent side streams
+    (ops.side_stream(dev, PREFIX_STREAM): main, forward chain / time decoder, weight gradients and this one fill the four
+    hardware queues HIP gives a process).  Measured and rejected (profiles/r06_prefix_pipeline.log, same box, ms per C3
+    step; off = 77.3): a stream of the device's least priority (STCAT_PREFIX_PRIO=1) 94.8, a stream masked to 192 / 128 /
+    64 compute units (STCAT_PREFIX_CUS=n) 111-127 — a stream created beside torch's pool lands on a hardware queue that
+    one of the step's streams already uses and the two serialise (the node timeline shows the decoders waiting for the
+    whole prefix)."""
+    key = str(dev)
+    st = _PREFIX_LANES.get(key)
+    if st is None:
+        if PREFIX_CUS > 0 or PREFIX_PRIO != 0:
+            import ctypes
+            out = ctypes.c_void_p()
+            with torch.cuda.device(dev):
+                rc = ops.L.load().stcat_stream_create(PREFIX_PRIO, PREFIX_CUS, ctypes.byref(out))
+            if rc != 0 or not out.value:
+                raise ops.L.StcatHipError("stcat_stream_create failed: " + ops.L.load().stcat_last_error().decode())
+            st = torch.cuda.ExternalStream(out.value, device=dev)
+        else:
+            st = ops.side_stream(dev, PREFIX_STREAM)
+        _PREFIX_LANES[key] = st
+    return st
 
 
 def _prefix_blocks(body):
@@ -586,7 +617,7 @@ class Backbone(nn.Module):
         # the end of the backward node — precedes this point on the main stream.
         side = None
         if cuda and ops.FORK_ENABLED and ops.L._backend == "hip":
-            side = ops.side_stream(dev, PREFIX_STREAM)
+            side = _prefix_lane(dev)
             if side.cuda_stream == main.cuda_stream:
                 side = None
         with torch.no_grad():
@@ -626,6 +657,7 @@ class Backbone(nn.Module):
         return pre["x"]
 
     def features_nhwc(self, frames: torch.Tensor) -> torch.Tensor:
+        ops.drop_deferred()      # (a fill that the previous pass never reached — a model without our decoder: dropped)
         if self.training and torch.is_grad_enabled():
             # first module of the hot path to run in a step: open the step's dropout counter range (drop-in mode has
             # no other place to do it — the reference's train loop is unmodified)
@@ -642,7 +674,12 @@ class Backbone(nn.Module):
             self.prefix_stats["taken" if pre is not None else "inline"] += 1
             feat = plans.apply(_BackboneFnPl, frames, self.body, pre.t if pre is not None else None,
                                pre.mask if pre is not None else None, *weights)
-            self._fill()     # the NEXT clip's frozen prefix, if one was declared (stage_next), behind this forward
+            # the NEXT clip's frozen prefix, if one was declared (stage_next): behind this forward — at once, or handed to
+            # the query decoder's entry (ops.run_deferred in QueryDecoder.run), where the chip has room for it
+            if PREFIX_AT == "decoder" and self._staged is not None:
+                ops.defer(self._fill)
+            else:
+                self._fill()
             return feat
         self._staged = None
         return plans.apply(_BackboneFn, frames, self.body, *weights)

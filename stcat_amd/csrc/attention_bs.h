@@ -96,17 +96,109 @@ static __device__ __forceinline__ void stcat_abs_split_regs(const f32x16& x, int
   ACC = STCAT_MFMA_BF16_32x32x16(AH, BL, ACC);              \
   ACC = STCAT_MFMA_BF16_32x32x16(AH, BH, ACC);
 
+// ---- NP-plane forms (round 6).  NP = 2: the three-product split above (modes bf16x3 / bf16x3p / bf16x6).  NP = 3: x = p0 + p1 + p2
+// EXACTLY (every residual of the split is exact in fp32) and a product keeps the six cross terms down to 2^-16 relative —
+// p0 q0 + p0 q1 + p1 q0 + p1 q1 + p0 q2 + p2 q0 — the arithmetic of the plane GEMMs of mode bf16x6p (igemm_pl.h), issued
+// smallest terms first.  Mode bf16x6p's self-attention ran on the fp32 matrix pipe (attention.h: 64-cycle MFMAs, the S x S
+// probabilities and their gradient stashed in HBM: 397 MB read per backward launch at C3); with NP = 3 it runs here.
+template <int NP> struct AbsFrag { bf16x8 p[NP]; };
+
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_split8(const float* x, AbsFrag<NP>& f) {
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    float r = x[e];
+    STCAT_UNROLL
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 b = (__bf16)r;
+      f.p[q][e] = b;
+      r -= (float)b;
+    }
+  }
+}
+
+// registers 8 j .. 8 j + 7 of an accumulator tile -> NP B-operand fragments
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_split_acc(const f32x16& x, int j, AbsFrag<NP>& f) {
+  float v[8];
+  STCAT_UNROLL
+  for (int e = 0; e < 8; ++e) v[e] = x[8 * j + e];
+  stcat_abs_split8<NP>(v, f);
+}
+
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_mma(f32x16& acc, const AbsFrag<NP>& a, const AbsFrag<NP>& b) {
+  if constexpr (NP == 3) {
+    acc = STCAT_MFMA_BF16_32x32x16(a.p[2], b.p[0], acc);
+    acc = STCAT_MFMA_BF16_32x32x16(a.p[0], b.p[2], acc);
+    acc = STCAT_MFMA_BF16_32x32x16(a.p[1], b.p[1], acc);
+  }
+  acc = STCAT_MFMA_BF16_32x32x16(a.p[1], b.p[0], acc);
+  acc = STCAT_MFMA_BF16_32x32x16(a.p[0], b.p[1], acc);
+  acc = STCAT_MFMA_BF16_32x32x16(a.p[0], b.p[0], acc);
+}
+
+// stage rows [r0, r0 + ROWS) of a [S][ld] fp32 matrix (32 columns of one head) as NP swizzled planes at base + q * plane_bytes
+template <int ROWS, int NP>
+static __device__ __forceinline__ void stcat_abs_stage_n(const float* g, int ld, int r0, int S, char* base, int plane_bytes,
+                                                         int t, int nthr, float mul) {
+  for (int i = t; i < ROWS * 8; i += nthr) {
+    const int r = i >> 3, c4 = i & 7;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < S) v = stcat_ld4(g + (long)(r0 + r) * ld + c4 * 4);
+    float x[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
+    const unsigned off = stcat_abs_off(r, c4 >> 1) + (c4 & 1) * 8;
+    STCAT_UNROLL
+    for (int q = 0; q < NP; ++q) {
+      bf16x4 w;
+      STCAT_UNROLL
+      for (int e = 0; e < 4; ++e) {
+        const __bf16 b = (__bf16)x[e];
+        w[e] = b;
+        x[e] -= (float)b;
+      }
+      *reinterpret_cast<bf16x4*>(base + q * plane_bytes + off) = w;
+    }
+  }
+}
+
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_rowfrag_n(const char* base, int plane_bytes, int r, int c, AbsFrag<NP>& f) {
+  STCAT_UNROLL
+  for (int q = 0; q < NP; ++q) f.p[q] = STCAT_ABS_ROWFRAG(base + q * plane_bytes, r, c);
+}
+
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_trfrag_n(const char* base, int plane_bytes, int t0, int lane, AbsFrag<NP>& f) {
+  STCAT_UNROLL
+  for (int q = 0; q < NP; ++q) f.p[q] = stcat_abs_trfrag(base + q * plane_bytes, t0, lane);
+}
+
+// this lane's 16 values of a [S][ld] fp32 row block (row `row`, head dims 16 s + 8 hi .. + 7 for k-step s), times mul, as planes
+template <int NP>
+static __device__ __forceinline__ void stcat_abs_rowregs(const float* g, int ld, int row, int S, int hi, float mul,
+                                                         AbsFrag<NP> (&f)[2]) {
+  STCAT_UNROLL
+  for (int s = 0; s < 2; ++s) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (row < S) { a = stcat_ld4(g + (long)row * ld + 16 * s + 8 * hi); c = stcat_ld4(g + (long)row * ld + 16 * s + 8 * hi + 4); }
+    const float x[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, c.x * mul, c.y * mul, c.z * mul, c.w * mul};
+    stcat_abs_split8<NP>(x, f[s]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward: grid (B*H, ceil(query tiles / NW)), NW waves, one 32-query tile per wave; keys stream through LDS in
-// super-chunks of 256 (one for S <= 256), consumed in chunks of 128 with the online-softmax update
+// super-chunks of 256 (one for S <= 256), consumed in chunks of 128 with the online-softmax update.  NP planes per operand
+// (2 x NP x 16 KB of LDS + the key bias).
 // ---------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int NP>
 __global__ void __launch_bounds__(64 * NW) mha_bs_fwd_kernel(AttnBsParams p) {
   p.drop = stcat_drop_resolve(p.drop);
-  constexpr int SC = 256, PLANE = SC * STCAT_ABS_ROWB;  // 16 KB per plane; 4 planes + key bias = 65 KB (dynamic LDS)
+  constexpr int SC = 256, PLANE = SC * STCAT_ABS_ROWB;  // 16 KB per plane
   STCAT_DYN_SHARED(char, smem);
-  char* Kh = smem; char* Kl = smem + PLANE; char* Vh = smem + 2 * PLANE; char* Vl = smem + 3 * PLANE;
-  float* kb = reinterpret_cast<float*>(smem + 4 * PLANE);
+  char* Kp = smem; char* Vp = smem + NP * PLANE;
+  float* kb = reinterpret_cast<float*>(smem + 2 * NP * PLANE);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int SP = ((p.S + 31) / 32) * 32;
@@ -115,31 +207,16 @@ __global__ void __launch_bounds__(64 * NW) mha_bs_fwd_kernel(AttnBsParams p) {
   const float* Kg = p.K + (long)b * p.S * p.ldk + h * 32;
   const float* Vg = p.V + (long)b * p.S * p.ldv + h * 32;
   // this lane's query row, head dims 16 s + 8 hi .. + 7 for k-step s, pre-scaled (attention.py:283-285), split
-  bf16x8 qh[2], ql[2];
-  {
-    const float* Qg = p.Q + ((long)b * p.S + q) * p.ldq + h * 32;
-    STCAT_UNROLL
-    for (int s = 0; s < 2; ++s) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-      if (q < p.S) { a = stcat_ld4(Qg + 16 * s + 8 * hi); c = stcat_ld4(Qg + 16 * s + 8 * hi + 4); }
-      const float x[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-      STCAT_UNROLL
-      for (int e = 0; e < 8; ++e) {
-        const float v = x[e] * p.scale;
-        const __bf16 hh = (__bf16)v;
-        qh[s][e] = hh;
-        ql[s][e] = (__bf16)(v - (float)hh);
-      }
-    }
-  }
+  AbsFrag<NP> qf[2];
+  stcat_abs_rowregs<NP>(p.Q + (long)b * p.S * p.ldq + h * 32, p.ldq, q, p.S, hi, p.scale, qf);
   f32x16 o;
   STCAT_UNROLL
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m = STCAT_NEG_INF, l = 0.f;
   for (int sc0 = 0; sc0 < p.S; sc0 += SC) {
     if (sc0) __syncthreads();  // everybody is done with the previous super-chunk
-    stcat_abs_stage<SC>(Kg, p.ldk, sc0, p.S, Kh, Kl, t, 64 * NW, 1.f);
-    stcat_abs_stage<SC>(Vg, p.ldv, sc0, p.S, Vh, Vl, t, 64 * NW, 1.f);
+    stcat_abs_stage_n<SC, NP>(Kg, p.ldk, sc0, p.S, Kp, PLANE, t, 64 * NW, 1.f);
+    stcat_abs_stage_n<SC, NP>(Vg, p.ldv, sc0, p.S, Vp, PLANE, t, 64 * NW, 1.f);
     for (int i = t; i < SC; i += 64 * NW)
       kb[i] = (sc0 + i < p.S && !(p.kpm && p.kpm[(long)b * p.S + sc0 + i])) ? 0.f : STCAT_NEG_INF;
     __syncthreads();
@@ -156,8 +233,9 @@ __global__ void __launch_bounds__(64 * NW) mha_bs_fwd_kernel(AttnBsParams p) {
         if (sc0 + k0 < p.S) {  // tile-uniform
           STCAT_UNROLL
           for (int s = 0; s < 2; ++s) {
-            const bf16x8 kh = STCAT_ABS_ROWFRAG(Kh, k0 + l31, 2 * s + hi), kl = STCAT_ABS_ROWFRAG(Kl, k0 + l31, 2 * s + hi);
-            STCAT_ABS_MMA3(sc[kt], kh, kl, qh[s], ql[s])
+            AbsFrag<NP> kf;
+            stcat_abs_rowfrag_n<NP>(Kp, PLANE, k0 + l31, 2 * s + hi, kf);
+            stcat_abs_mma<NP>(sc[kt], kf, qf[s]);
           }
           STCAT_UNROLL
           for (int r = 0; r < 16; ++r) {
@@ -201,10 +279,10 @@ __global__ void __launch_bounds__(64 * NW) mha_bs_fwd_kernel(AttnBsParams p) {
         }
         STCAT_UNROLL
         for (int j = 0; j < 2; ++j) {
-          bf16x8 ph, pl_;
-          stcat_abs_split_regs(sc[kt], j, ph, pl_);
-          const bf16x8 vh = stcat_abs_trfrag(Vh, k0 + 16 * j, lane), vl = stcat_abs_trfrag(Vl, k0 + 16 * j, lane);
-          STCAT_ABS_MMA3(o, vh, vl, ph, pl_)
+          AbsFrag<NP> pf, vf;
+          stcat_abs_split_acc<NP>(sc[kt], j, pf);
+          stcat_abs_trfrag_n<NP>(Vp, PLANE, k0 + 16 * j, lane, vf);
+          stcat_abs_mma<NP>(o, vf, pf);
         }
       }
     }
@@ -358,6 +436,165 @@ __global__ void __launch_bounds__(64 * NW) mha_bs_bwd_kernel(AttnBsParams p, con
         stcat_st4(gv + 8 * c, make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]));
         stcat_st4(gk + 8 * c, make_float4(dk[4 * c], dk[4 * c + 1], dk[4 * c + 2], dk[4 * c + 3]));
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward in TWO launches (round 6; any NP, used for NP = 3 where Q, K, V, dO as three planes each would be 172 KB of LDS
+// at S = 224): the probabilities are recomputed on the bf16 pipe from the row log-sum-exp in both.
+//   dQ kernel:    wave = query tile.  K, V planes in LDS (2 NP planes), this wave's Q (pre-scaled) and dO rows split in
+//                 registers straight from HBM, delta_q = dO_q . O_q from the same rows.
+//   dK/dV kernel: wave = key tile.  Q (pre-scaled), dO planes in LDS, this wave's K and V rows in registers.
+// One workgroup per (batch, head), NW = ceil(S / 32) waves, S <= 256.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int NP>
+__global__ void __launch_bounds__(64 * NW) mha_bs_bwd_dq_kernel(AttnBsParams p, const float* Og) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int SPc = NW * 32, PLANE = SPc * STCAT_ABS_ROWB;
+  STCAT_DYN_SHARED(char, smem);
+  char* Kp = smem; char* Vp = smem + NP * PLANE;
+  float* kb = reinterpret_cast<float*>(smem + 2 * NP * PLANE);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int SP = ((p.S + 31) / 32) * 32;
+  stcat_abs_stage_n<SPc, NP>(p.K + (long)b * p.S * p.ldk + h * 32, p.ldk, 0, p.S, Kp, PLANE, t, 64 * NW, 1.f);
+  stcat_abs_stage_n<SPc, NP>(p.V + (long)b * p.S * p.ldv + h * 32, p.ldv, 0, p.S, Vp, PLANE, t, 64 * NW, 1.f);
+  for (int i = t; i < SPc; i += 64 * NW) kb[i] = (i < p.S && !(p.kpm && p.kpm[(long)b * p.S + i])) ? 0.f : STCAT_NEG_INF;
+  const int q = wave * 32 + l31;
+  AbsFrag<NP> qf[2], gf[2];
+  stcat_abs_rowregs<NP>(p.Q + (long)b * p.S * p.ldq + h * 32, p.ldq, q, p.S, hi, p.scale, qf);
+  stcat_abs_rowregs<NP>(p.dO + (long)b * p.S * p.ldo + h * 32, p.ldo, q, p.S, hi, 1.f, gf);
+  float dq_ = 0.f, lq = 0.f;
+  if (q < p.S) {
+    const float* g = p.dO + ((long)b * p.S + q) * p.ldo + h * 32 + 16 * hi;     // (half a row per lane of the pair)
+    const float* og = Og + ((long)b * p.S + q) * p.ldo + h * 32 + 16 * hi;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = stcat_ld4(g + 4 * c), o4 = stcat_ld4(og + 4 * c);
+      dq_ += a.x * o4.x + a.y * o4.y + a.z * o4.z + a.w * o4.w;
+    }
+    lq = p.lse[(long)blockIdx.x * p.S + q];
+  }
+  dq_ += __shfl_xor(dq_, 32);
+  __syncthreads();
+  f32x16 dq;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  for (int kt = 0; kt < NW; ++kt) {
+    const int k0 = kt * 32;
+    f32x16 s_, dp;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
+    STCAT_UNROLL
+    for (int s = 0; s < 2; ++s) {
+      AbsFrag<NP> kf, vf;
+      stcat_abs_rowfrag_n<NP>(Kp, PLANE, k0 + l31, 2 * s + hi, kf);
+      stcat_abs_rowfrag_n<NP>(Vp, PLANE, k0 + l31, 2 * s + hi, vf);
+      stcat_abs_mma<NP>(s_, kf, qf[s]);
+      stcat_abs_mma<NP>(dp, vf, gf[s]);
+    }
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = (q < p.S) ? __expf(s_[r] + kb[key] - lq) : 0.f;   // masked / padded keys: exp(-inf) = 0
+      float dpv = dp[r];
+      if (p.drop.thresh) dpv *= stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + q);
+      s_[r] = pr * (dpv - dq_);                                          // dS (the scale rides in the staged Q / below)
+    }
+    STCAT_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      AbsFrag<NP> df, ktf;
+      stcat_abs_split_acc<NP>(s_, j, df);
+      stcat_abs_trfrag_n<NP>(Kp, PLANE, k0 + 16 * j, lane, ktf);
+      stcat_abs_mma<NP>(dq, ktf, df);
+    }
+  }
+  if (q < p.S) {
+    float* g = p.dQ + ((long)b * p.S + q) * p.ldg + h * 32 + 4 * hi;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c)
+      stcat_st4(g + 8 * c, make_float4(dq[4 * c] * p.scale, dq[4 * c + 1] * p.scale, dq[4 * c + 2] * p.scale,
+                                       dq[4 * c + 3] * p.scale));
+  }
+}
+
+template <int NW, int NP>
+__global__ void __launch_bounds__(64 * NW) mha_bs_bwd_dkv_kernel(AttnBsParams p, const float* Og) {
+  p.drop = stcat_drop_resolve(p.drop);
+  constexpr int SPc = NW * 32, PLANE = SPc * STCAT_ABS_ROWB;
+  STCAT_DYN_SHARED(char, smem);
+  char* Qp = smem; char* Gp = smem + NP * PLANE;
+  float* lse = reinterpret_cast<float*>(smem + 2 * NP * PLANE);
+  float* dlt = lse + SPc;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int SP = ((p.S + 31) / 32) * 32;
+  stcat_abs_stage_n<SPc, NP>(p.Q + (long)b * p.S * p.ldq + h * 32, p.ldq, 0, p.S, Qp, PLANE, t, 64 * NW, p.scale);
+  stcat_abs_stage_n<SPc, NP>(p.dO + (long)b * p.S * p.ldo + h * 32, p.ldo, 0, p.S, Gp, PLANE, t, 64 * NW, 1.f);
+  for (int i = t; i < SPc; i += 64 * NW) {
+    float d = 0.f, ls = 0.f;
+    if (i < p.S) {
+      const float* g = p.dO + ((long)b * p.S + i) * p.ldo + h * 32;
+      const float* og = Og + ((long)b * p.S + i) * p.ldo + h * 32;
+      STCAT_UNROLL
+      for (int c = 0; c < 8; ++c) {
+        const float4 a = stcat_ld4(g + 4 * c), o4 = stcat_ld4(og + 4 * c);
+        d += a.x * o4.x + a.y * o4.y + a.z * o4.z + a.w * o4.w;
+      }
+      ls = p.lse[(long)blockIdx.x * p.S + i];
+    }
+    dlt[i] = d;
+    lse[i] = ls;
+  }
+  const int key = wave * 32 + l31;
+  AbsFrag<NP> kf[2], vf[2];
+  stcat_abs_rowregs<NP>(p.K + (long)b * p.S * p.ldk + h * 32, p.ldk, key, p.S, hi, 1.f, kf);
+  stcat_abs_rowregs<NP>(p.V + (long)b * p.S * p.ldv + h * 32, p.ldv, key, p.S, hi, 1.f, vf);
+  const float kbias = (key < p.S && !(p.kpm && p.kpm[(long)b * p.S + key])) ? 0.f : STCAT_NEG_INF;
+  __syncthreads();
+  f32x16 dv, dk;
+  STCAT_UNROLL
+  for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+  for (int qt = 0; qt < NW; ++qt) {
+    const int q0 = qt * 32;
+    f32x16 s_, dp;
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
+    STCAT_UNROLL
+    for (int s = 0; s < 2; ++s) {
+      AbsFrag<NP> af, bf;
+      stcat_abs_rowfrag_n<NP>(Qp, PLANE, q0 + l31, 2 * s + hi, af);
+      stcat_abs_rowfrag_n<NP>(Gp, PLANE, q0 + l31, 2 * s + hi, bf);
+      stcat_abs_mma<NP>(s_, af, kf[s]);   // S[q][key]
+      stcat_abs_mma<NP>(dp, bf, vf[s]);   // dP[q][key] = dO_q . V_key
+    }
+    STCAT_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float pr = (qq < p.S) ? __expf(s_[r] + kbias - lse[qq]) : 0.f;
+      const float dm = p.drop.thresh ? stcat_drop_mul(p.drop, ((unsigned long long)blockIdx.x * SP + key) * SP + qq) : 1.f;
+      s_[r] = pr * (dp[r] * dm - dlt[qq]);   // dS[q][key]
+      dp[r] = pr * dm;                        // P' (dropped probabilities) for dV
+    }
+    STCAT_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      AbsFrag<NP> pf, df, gtf, qtf;
+      stcat_abs_split_acc<NP>(dp, j, pf);
+      stcat_abs_split_acc<NP>(s_, j, df);
+      stcat_abs_trfrag_n<NP>(Gp, PLANE, q0 + 16 * j, lane, gtf);
+      stcat_abs_trfrag_n<NP>(Qp, PLANE, q0 + 16 * j, lane, qtf);
+      stcat_abs_mma<NP>(dv, gtf, pf);   // dV^T[d][key] += dO^T[d][q] P'[q][key]
+      stcat_abs_mma<NP>(dk, qtf, df);   // dK^T[d][key] += (scale Q)^T[d][q] dS[q][key]
+    }
+  }
+  if (key < p.S) {
+    float* gv = p.dV + ((long)b * p.S + key) * p.ldgv + h * 32 + 4 * hi;
+    float* gk = p.dK + ((long)b * p.S + key) * p.ldg + h * 32 + 4 * hi;
+    STCAT_UNROLL
+    for (int c = 0; c < 4; ++c) {
+      stcat_st4(gv + 8 * c, make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]));
+      stcat_st4(gk + 8 * c, make_float4(dk[4 * c], dk[4 * c + 1], dk[4 * c + 2], dk[4 * c + 3]));
     }
   }
 }

@@ -713,6 +713,43 @@ int stcat_spin(int microseconds, void* stream) {
   return launch_status();
 }
 
+// A HIP stream for a background lane of the step (round 6: the next clip's frozen prefix under the grounding section).
+// priority: -1 = the device's greatest, 0 = default, 1 = the device's least (the command processor serves the queues of a
+// higher class first, so a least-priority lane gives way to the dependent chains it runs under); cus > 0: restrict the
+// stream to `cus` compute units (hipExtStreamCreateWithCUMask: the first `cus` bits of the mask) — the chains always find
+// free CUs, and the lane draws proportionally less HBM bandwidth.  A CU mask and a priority cannot be combined (HIP has no
+// such constructor): cus wins.  Returns the hipStream_t in *out; the caller owns it (stcat_stream_destroy).
+int stcat_stream_create(int priority, int cus, void** out) {
+  if (!out) return fail("stream_create: out is null");
+  *out = nullptr;
+#ifdef STCAT_EMU
+  (void)priority; (void)cus;
+  return 0;                      // (the emulator has no streams: every launch is synchronous)
+#else
+  hipStream_t st = nullptr;
+  if (cus > 0) {
+    if (cus > 1024) return fail("stream_create: cus = %d", cus);
+    uint32_t mask[32] = {0};
+    for (int i = 0; i < cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    if (hipExtStreamCreateWithCUMask(&st, 32, mask) != hipSuccess) return fail("stream_create: hipExtStreamCreateWithCUMask failed");
+  } else {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return fail("stream_create: no priority range");
+    const int pr = priority < 0 ? greatest : (priority > 0 ? least : 0);
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr) != hipSuccess) return fail("stream_create: hipStreamCreateWithPriority failed");
+  }
+  *out = (void*)st;
+  return 0;
+#endif
+}
+
+int stcat_stream_destroy(void* stream) {
+#ifndef STCAT_EMU
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return fail("stream_destroy failed");
+#endif
+  return 0;
+}
+
 int stcat_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                          float* bias, int C, float eps, void* stream) {
   if (C <= 0) return fail("frozen_bn_fold: C=%d", C);
@@ -1686,6 +1723,9 @@ int stcat_weight_planes_multi(const void* table, int n_entries, int total_blocks
     default: { constexpr int NW = 8; CALL; } break;                  \
   }
 
+// planes per operand of the bf16-pipe self-attention: 3 (six products, fp32-class) in mode bf16x6p, else 2 (three products)
+static int mha_bs_planes() { return g_mma_mode_raw == 5 ? 3 : 2; }
+
 int stcat_mha_bs_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
                      int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p, long drop_seed,
                      long drop_offset, const long* drop_base, void* stream) {
@@ -1697,11 +1737,19 @@ int stcat_mha_bs_fwd(const float* q, const float* k, const float* v, const unsig
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   const int nq = cdiv(S, 32), nw = nq < 8 ? nq : 8;
-  const int lds = 4 * 256 * 64 + 256 * 4;
   hipStream_t st = (hipStream_t)stream;
+  if (mha_bs_planes() == 3) {      // mode bf16x6p: three planes per operand, six products (round 6)
+    const int lds = 6 * 256 * 64 + 256 * 4;
+    STCAT_NW_SWITCH(nw, {
+      if (int rc = pl_prepare(mha_bs_fwd_kernel<NW, 3>, lds)) return rc;
+      STCAT_LAUNCH((mha_bs_fwd_kernel<NW, 3>), dim3(B * H, cdiv(nq, nw)), dim3(64 * NW), lds, st, p);
+    })
+    return launch_status();
+  }
+  const int lds = 4 * 256 * 64 + 256 * 4;
   STCAT_NW_SWITCH(nw, {
-    if (int rc = pl_prepare(mha_bs_fwd_kernel<NW>, lds)) return rc;
-    STCAT_LAUNCH((mha_bs_fwd_kernel<NW>), dim3(B * H, cdiv(nq, nw)), dim3(64 * NW), lds, st, p);
+    if (int rc = pl_prepare(mha_bs_fwd_kernel<NW, 2>, lds)) return rc;
+    STCAT_LAUNCH((mha_bs_fwd_kernel<NW, 2>), dim3(B * H, cdiv(nq, nw)), dim3(64 * NW), lds, st, p);
   })
   return launch_status();
 }
@@ -1718,8 +1766,20 @@ int stcat_mha_bs_bwd(const float* q, const float* k, const float* v, const unsig
   p.B = B; p.H = H; p.S = S; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ldg = ldg; p.ldgv = ldgv; p.scale = scale;
   p.drop = stcat_make_drop(drop_p, drop_seed, drop_offset, drop_base);
   const int nw = cdiv(S, 32);
-  const int lds = 8 * nw * 32 * 64 + 3 * nw * 32 * 4;
   hipStream_t st = (hipStream_t)stream;
+  if (mha_bs_planes() == 3) {
+    // three planes of Q, K, V, dO do not fit one workgroup's LDS (172 KB at S = 224): dQ and dK / dV as two launches, each
+    // with two operands as planes in LDS (86 KB) and its own tile's rows in registers
+    const int lds = 6 * nw * 32 * 64 + 2 * nw * 32 * 4;
+    STCAT_NW_SWITCH(nw, {
+      if (int rc = pl_prepare(mha_bs_bwd_dq_kernel<NW, 3>, lds)) return rc;
+      if (int rc = pl_prepare(mha_bs_bwd_dkv_kernel<NW, 3>, lds)) return rc;
+      STCAT_LAUNCH((mha_bs_bwd_dq_kernel<NW, 3>), dim3(B * H), dim3(64 * NW), lds, st, p, out);
+      STCAT_LAUNCH((mha_bs_bwd_dkv_kernel<NW, 3>), dim3(B * H), dim3(64 * NW), lds, st, p, out);
+    })
+    return launch_status();
+  }
+  const int lds = 8 * nw * 32 * 64 + 3 * nw * 32 * 4;
   STCAT_NW_SWITCH(nw, {
     if (int rc = pl_prepare(mha_bs_bwd_kernel<NW>, lds)) return rc;
     STCAT_LAUNCH((mha_bs_bwd_kernel<NW>), dim3(B * H), dim3(64 * NW), lds, st, p, out);

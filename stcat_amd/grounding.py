@@ -443,12 +443,16 @@ class QueryDecoder(plans.InvalidatesPlans, nn.Module):
         n, S, d = memory.shape
         T = frames_cls.shape[0]
         assert n == T
+        ops.run_deferred()       # (round 6: the next clip's frozen backbone prefix starts here, under the decoders' chains)
         pos_query, temp_query = self.template_generator.run(frames_cls, video_cls)          # :97-99
         anchor = ops.sigmoid(pos_query)                                                      # :101
         time_embed = self.time_embed(T)[:, 0, :]                                             # :120
         # The box decoder and the time decoder are independent chains of ~650 tiny, latency-bound launches each
         # (6 sequential layers on [T,256] states): the time decoder runs on a second HIP stream so the two chains
         # overlap on the GPU.  Autograd replays each backward node on its forward stream, so backward overlaps too.
+        # (measured and rejected, round 6: both decoder chains on streams of the device's GREATEST priority while the next
+        #  clip's backbone prefix runs beside them — 105.4 / 106.0 ms per C3 step against 76.7 / 77.1; like every stream
+        #  created outside the measured set they serialise with one of the step's queues: profiles/r06_prefix_pipeline.log)
         fork = ops.fork_stream(memory)
         with fork:
             if composite.ENABLED:

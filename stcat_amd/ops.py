@@ -203,6 +203,29 @@ def _wait_stream(waiter, signal) -> None:
         L.RECORDER.wait(waiter, signal)
 
 
+# ------------------------------------------------------------------------------------
+# work queued by one module of the path for a later point of the same forward pass
+# ------------------------------------------------------------------------------------
+_DEFERRED = []
+
+
+def defer(fn) -> None:
+    """`fn()` runs at the next `run_deferred()` — the visual encoder hands the next clip's frozen prefix (Backbone._fill) to
+    the query decoder's entry this way: launched there, it runs under the decoders' latency-bound chains instead of
+    competing with the encoder's full-chip GEMMs (measured: issued right behind the backbone it doubled the encoder's
+    forward, 3.3 -> 6.5 ms; profiles/r06_prefix_pipeline.log)"""
+    _DEFERRED.append(fn)
+
+
+def run_deferred() -> None:
+    while _DEFERRED:
+        _DEFERRED.pop(0)()
+
+
+def drop_deferred() -> None:
+    _DEFERRED.clear()
+
+
 def host_call(fn):
     """run a host-side action that belongs at this point of a node's launch sequence (a launch plan replays it here)"""
     if L.RECORDER is not None:
@@ -895,6 +918,7 @@ def _ld3(t: torch.Tensor) -> int:
 # MFMAs per wave — measured +0.25 ms per C3 step (profiles/r05_as_kernel_experiments.log, item 8); it halves the
 # attention's activation memory, which is what it is kept for.
 MHA_RECOMPUTE = bool(os.environ.get("STCAT_MHA_RECOMPUTE"))
+MHA_FP32_PIPE = bool(os.environ.get("STCAT_MHA_FP32_PIPE"))      # A/B switch: every mode's self-attention on the fp32-pipe kernels
 
 
 class MhaSelfFn(Function):
@@ -921,7 +945,9 @@ class MhaSelfFn(Function):
         # (mode bf16x6p is fp32-class end to end: its attention runs on the fp32 matrix pipe as well)
         # rows longer than 256 tokens (non-square clips) train through the fp32 long-row kernels in every mode: the
         # bf16-pipe backward keeps a whole row's tiles in LDS and is built for S <= 256
-        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "bf16x6p", "f16x3p")
+        # (round 6: mode bf16x6p runs here too — three planes per operand, six products: csrc/attention_bs.h, NP = 3; the
+        #  frozen experimental mode f16x3p keeps the fp32-pipe kernels)
+        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "f16x3p") and not MHA_FP32_PIPE
                   and (S <= 256 or not any(ctx.needs_input_grad[:3])))
         if ctx.bs:
             keep = any(ctx.needs_input_grad[:3])

@@ -836,6 +836,47 @@ def _mha_bs(dev, big):
         L.set_mma_mode("f32")
 
 
+@both
+def _mha_bs_six_products(dev, big):
+    """Round 6: mode bf16x6p's self-attention on the bf16 pipe (csrc/attention_bs.h, NP = 3): Q, K, V, the probabilities and
+    dS as three bf16 planes (their sum IS the fp32 value), six products per contraction, fp32 accumulate; forward keeps the
+    row log-sum-exp only, backward = two launches (dQ; dK / dV) that recompute the probabilities.  Checked against the
+    fp32 PyTorch reference with the fp32 kernels' tolerance (TOL), and — what tells six products from three — much closer to
+    an fp64 evaluation than the three-product kernel is."""
+    L.set_mma_mode("bf16x6p")
+    try:
+        _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)       # two key tiles, ragged
+        _mha_case(dev, 1, 65, 1, need_w=False, packed=False, masked=True)      # temporal-layer shape (T + 1)
+        _mha_case(dev, 1, 150, 2, need_w=False, packed=True, masked=True)      # two 128-key chunks: online rescale
+        _mha_case(dev, 1, 8, 2, need_w=True, packed=True, masked=False)        # head-mean weights wanted: fp32-pipe kernels
+        _mha_dropout_case(dev, 2, 37, 2, need_w=False)
+        _mha_case(dev, 1, 310, 1, need_w=False, packed=True, masked=True)      # > 256 tokens with gradients: long-row kernels
+        # accuracy class: error against fp64, six products (this mode) vs three (mode bf16x3)
+        B, S, H = 1, 96, 2
+        D = H * 32
+        qk, v, go = rnd(B, S, 2 * D, seed=31) * 2.0, rnd(B, S, D, seed=32), rnd(B, S, D, seed=33)
+        qk64, v64 = qk.double().requires_grad_(True), v.double().requires_grad_(True)
+        o64, _ = _mha_ref(qk64[..., :D], qk64[..., D:], v64, None, 32 ** -0.5, H)
+        (o64 * go.double()).sum().backward()
+        errs = {}
+        for mode in ("bf16x6p", "bf16x3"):
+            L.set_mma_mode(mode)
+            a, b_ = qk.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+            o, _ = ops.mha_self_packed(a, b_, None, 32 ** -0.5)
+            (o * go.to(dev)).sum().backward()
+            errs[mode] = tuple(((x.detach().double().cpu() - y.detach()).abs().max() / y.detach().abs().max()).item()
+                               for x, y in ((o, o64), (a.grad, qk64.grad), (b_.grad, v64.grad)))
+        L.set_mma_mode("bf16x6p")
+        assert max(errs["bf16x6p"]) < 3e-6, errs                     # fp32-class (an fp32 evaluation itself: ~1e-6)
+        assert max(errs["bf16x6p"]) < 0.2 * max(errs["bf16x3"]), errs
+        if big:
+            _mha_case(dev, 64, 207, 8, need_w=False, packed=True, masked=True)  # the C3 spatial layer
+            _mha_case(dev, 2, 256, 8, need_w=False, packed=True, masked=False)
+            _mha_dropout_case(dev, 4, 207, 8, need_w=False, pdrop=0.1)
+    finally:
+        L.set_mma_mode("f32")
+
+
 def _q1_dropout_case(dev, B, S, H, pdrop=0.25):
     D = H * 32
     q1, k1, v = rnd(B, D, seed=1), rnd(B, S, D, seed=3), rnd(B, S, D, seed=5)

@@ -381,13 +381,15 @@ def _prefix_pipeline_case(dev, T, res, steps, train, tol, grad_l2):
             if mode == "pipelined":
                 st = bb.prefix_stats
                 # step 0 computes in place (nothing staged before it), step 3 too (its frames changed after staging)
-                assert st["inline"] == 2 and st["taken"] == steps - 2, st
+                n_inline = 2 if steps > 3 else 1       # (step 0; step 3: its frames changed after they were staged)
+                assert st["inline"] == n_inline and st["taken"] == steps - n_inline, st
                 assert plans.STATS["replayed"] > 0, plans.STATS
             for c, b in zip(clips, base):
                 c.tensors.copy_(b)
         _check_equal(runs["plain"], runs["pipelined"], tol, grad_l2=grad_l2)
         # the clips do differ, and the rewritten visit differs from the first visit of the same clip
-        assert runs["plain"][0][1] != runs["plain"][1][1] and runs["plain"][1][1] != runs["plain"][3][1]
+        assert runs["plain"][0][1] != runs["plain"][1][1]
+        assert steps <= 3 or runs["plain"][1][1] != runs["plain"][3][1]
     finally:
         plans.enable(False)
         plans.clear()
@@ -395,7 +397,84 @@ def _prefix_pipeline_case(dev, T, res, steps, train, tol, grad_l2):
 
 
 def test_emu_prefix_pipeline_equals_unpipelined_steps():
-    _prefix_pipeline_case(use_emu(), 2, 32, 5, False, 2e-5, None)
+    """the whole model on the emulator, three steps (in place; staged, eager; staged, recorded).  Gradients by rel-L2: the
+    emulator's threads order the split-K atomics of the skinny forwards differently from run to run (1e-6 of noise between
+    two eager steps on one clip), and one FFN pre-activation of this tiny clip sits within that noise of its ReLU kink —
+    a single flipped mask element moves one row of linear1's gradient by 1e-2 (seen: bias gradient equal in 2047 of 2048
+    columns).  The backbone-level test below is the bit-exact one."""
+    _prefix_pipeline_case(use_emu(), 2, 32, 3, False, 2e-5, 3e-3)
+
+
+def _prefix_pipeline_backbone_bit_exact(dev, T, res, blocks):
+    """the visual encoder alone (no atomics on this path: the plane weight gradients are ordered sums): features and every
+    weight gradient of a pipelined step — eager, recorded and REPLAYED — are bit-identical to the un-pipelined step on the
+    same clip; two clips alternate, one is rewritten in place between two visits"""
+    from stcat_amd import backbone
+    _lib.set_mma_mode("bf16x6p")
+    saved = backbone.BLOCKS
+    if blocks is not None:
+        backbone.BLOCKS = blocks
+    try:
+        enc = backbone.build_vis_encoder(None)
+    finally:
+        backbone.BLOCKS = saved
+    try:
+        synth.fill_module_(enc)
+        enc.to(dev)
+        bb = enc[0]
+        g = torch.Generator().manual_seed(1)
+        clips = [torch.randn(T, 3, res, res, generator=g).to(dev) for _ in range(2)]
+        gy = torch.randn(T, res // 32, res // 32, 2048, generator=g).to(dev)
+
+        def step(frames):
+            for p in bb.parameters():
+                p.grad = None
+            f = bb.features_nhwc(frames)
+            ops.run_deferred()              # (what the query decoder's entry does in the full model)
+            f.backward(gy)
+            return f.detach().clone(), {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+
+        plans.clear()
+        plans.enable(False)
+        ref = [step(c) for c in clips]
+        plans.enable(True)
+        plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0)
+        for k in range(5):
+            cur = clips[k % 2]
+            bb.stage_next(clips[(k + 1) % 2])
+            f, gr = step(cur)
+            rf, rg = ref[k % 2]
+            assert torch.equal(f, rf), k
+            assert set(gr) == set(rg) and all(torch.equal(gr[n], rg[n]) for n in rg), k
+        assert bb.prefix_stats["inline"] == 3 and bb.prefix_stats["taken"] == 4, bb.prefix_stats
+        assert plans.STATS["replayed"] >= 2, plans.STATS
+        # a clip rewritten AFTER it was declared: the staged prefix is stale, the step computes in place and is still right
+        bb.stage_next(clips[1])
+        f, _ = step(clips[0])
+        clips[1].mul_(0.5)
+        plans.enable(False)
+        inline_before = bb.prefix_stats["inline"]
+        f1, _ = step(clips[1])
+        assert bb.prefix_stats["inline"] == inline_before + 1
+        bb.stage_next(None)
+        f2, _ = step(clips[1])
+        assert torch.equal(f1, f2) and not torch.equal(f1, ref[1][0])
+    finally:
+        plans.enable(False)
+        plans.clear()
+        _lib.set_mma_mode("f32")
+
+
+def test_emu_prefix_pipeline_backbone_bit_exact():
+    _prefix_pipeline_backbone_bit_exact(use_emu(), 2, 32, (1, 1, 2, 1))
+
+
+@pytest.mark.gpu
+def test_gpu_prefix_pipeline_backbone_bit_exact():
+    """the full ResNet-101 at T = 8, 224 x 224: the staged prefix is one whole-clip launch per conv on the side stream, the
+    in-step one two half-clip chains on two streams — bit-identical features and weight gradients"""
+    from tests.backends import use_hip
+    _prefix_pipeline_backbone_bit_exact(use_hip(), 8, 224, None)
 
 
 @pytest.mark.gpu
@@ -407,4 +486,8 @@ def test_gpu_prefix_pipeline_equals_unpipelined_steps():
 @pytest.mark.gpu
 def test_gpu_prefix_pipeline_train_mode():
     from tests.backends import use_hip
-    _prefix_pipeline_case(use_hip(), 8, 224, 6, True, 2e-4, 3e-3)
+    # (train mode at T = 8 in bf16x6p: a gradient is a sum over few samples and two runs of ONE schedule already differ by
+    #  single ReLU-kink flips behind the atomically ordered split-K sums of the grounding model — 3.0e-3 .. 6.2e-3 rel-L2 on
+    #  single backbone tensors seen between runs; that the pipelined prefix itself is bit-identical is what
+    #  test_gpu_prefix_pipeline_backbone_bit_exact checks, the eval-mode case above keeps the 3e-3 bar)
+    _prefix_pipeline_case(use_hip(), 8, 224, 6, True, 2e-4, 1.5e-2)
