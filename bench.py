@@ -74,6 +74,35 @@ def _flops(name, a):
     if name == "stcat_mha_self_bwd":
         B, H, S = a[12:15]
         return 2.0 * 4 * B * H * S * S * 32
+    # round 6: every other contraction entry point of the step (the whole-step figure of `roofline.whole_step`)
+    if name in ("stcat_mha_bs_fwd", "stcat_mha_self_fwd_lse"):
+        B, H, S = a[6:9]
+        return 2.0 * 2 * B * H * S * S * 32
+    if name in ("stcat_mha_bs_bwd", "stcat_mha_self_bwd_lse"):   # dV, dP, dQ, dK (the recomputed score tiles are not counted)
+        B, H, S = a[10:13]
+        return 2.0 * 4 * B * H * S * S * 32
+    if name == "stcat_pl_conv_wgrad_ws":
+        n, H, W, Cin, Cout, KH, KW, stride, pad = a[6:15]
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        return 2.0 * n * OH * OW * Cout * KH * KW * Cin
+    if name == "stcat_pl_conv_dgrad_cadd":
+        n, H, W, Cin, Cout = a[11:16]
+        return 2.0 * n * H * W * Cin * Cout
+    if name == "stcat_pl_linear_fwd":
+        return 2.0 * a[10] * a[11] * a[12]
+    if name == "stcat_pl_linear_dgrad_mask":
+        return 2.0 * a[9] * a[10] * a[11]
+    if name in ("stcat_linear_fwd_acc", "stcat_linear_fwd_drop"):
+        return 2.0 * a[5] * a[6] * a[7]
+    if name == "stcat_linear_dgrad_acc":
+        return 2.0 * a[4] * a[5] * a[6]
+    if name == "stcat_linear_dgrad_mask":
+        return 2.0 * a[7] * a[8] * a[9]
+    if name in ("stcat_linear_fwd_multi", "stcat_linear_dgrad_multi", "stcat_linear_wgrad_multi"):
+        return 2.0 * a[0] * a[33] * a[34] * a[35]
+    if name == "stcat_stem_u8_fwd":
+        n, H, W = a[7:10]
+        return 2.0 * n * (H // 2) * (W // 2) * 64 * 147
     return 0.0
 
 
@@ -542,7 +571,7 @@ def main():
                 "duration_note": "achieved / frac use the ISOLATED per-launch duration (instrumented step on one stream: "
                                  "kernels run one at a time); co_scheduled = the same launches inside the three-stream "
                                  "step, where kernels of other streams share the CUs; rocprofv3 kernel stats of both "
-                                 "schedules: profiles/r05_bench_c3_kernel_stats_{serial,bf16x6p}.csv",
+                                 "schedules: profiles/r06_bench_c3_kernel_stats_{serial,bf16x6p}.csv",
                 "algorithmic_gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3)}
         tr = _pmc_traffic(dom, args.mma)
         # `traffic`: HBM bytes per launch of the dominant kernel family (PMC FETCH_SIZE / WRITE_SIZE passes, see the
@@ -565,6 +594,16 @@ def main():
         mm_ms = sum(v["ms"] for v in agg_iso.values() if v["flop"] > 0)
         roof["all_mfma_kernels"] = {"tflops": round(mm / mm_ms / 1e9, 2), "ms": round(mm_ms, 2),
                                     "gflop_per_step": round(mm / 1e9, 1)}
+        # the WHOLE step against the matrix pipes — every contraction's algorithmic flops (convs, Linears,
+        # attention) over the timed step's wall clock: what fraction of the dense bf16 peak the step sustains, the same
+        # with the six MFMA flops this arithmetic issues per flop, and against the fp32 matrix pipe (the reference's own
+        # arithmetic could not run faster than frac_fp32_pipe = 1)
+        step_s = elapsed / args.steps
+        roof["whole_step"] = {"gflop_per_step": round(mm / 1e9, 1), "ms_per_step": round(1e3 * step_s, 2),
+                              "tflops": round(mm / step_s / 1e12, 2),
+                              "frac_bf16": round(mm / step_s / 1e12 / PEAK_TFLOPS_BF16_MFMA, 4),
+                              "issued_frac_bf16": round(mm * mult / step_s / 1e12 / PEAK_TFLOPS_BF16_MFMA, 4),
+                              "frac_fp32_pipe": round(mm / step_s / 1e12 / PEAK_TFLOPS_F32_MFMA, 4)}
         gemm_shapes = prof_iso.shape_table()
     if comm:
         dist.barrier()
@@ -792,6 +831,7 @@ def main():
                          "blocks while the launch queue is full (the host runs ahead of a GPU-bound step); the host's own "
                          "work is the C1 line of profiles/r03_bench_variants.log (same launch sequence, ~no GPU work)",
             "streams": ops.PICK_REPORT.get(str(dev)),
+            "prefix_lane": __import__("stcat_amd.backbone", fromlist=["x"]).PREFIX_LANE_REPORT.get(str(dev)),
             "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 tensors, bf16x3 split products, f32 accumulate",

@@ -150,17 +150,56 @@ def _prefix_lane(dev):
     st = _PREFIX_LANES.get(key)
     if st is None:
         if PREFIX_CUS > 0 or PREFIX_PRIO != 0:
-            import ctypes
-            out = ctypes.c_void_p()
-            with torch.cuda.device(dev):
-                rc = ops.L.load().stcat_stream_create(PREFIX_PRIO, PREFIX_CUS, ctypes.byref(out))
-            if rc != 0 or not out.value:
-                raise ops.L.StcatHipError("stcat_stream_create failed: " + ops.L.load().stcat_last_error().decode())
-            st = torch.cuda.ExternalStream(out.value, device=dev)
-        else:
+            st = _probed_lane(dev)
+        if st is None:
             st = ops.side_stream(dev, PREFIX_STREAM)
         _PREFIX_LANES[key] = st
     return st
+
+
+def _probed_lane(dev):
+    """A stream made by stcat_stream_create (CU mask / priority) that does NOT share a hardware queue with the main stream,
+    the forward-chain / time-decoder stream or the weight-gradient stream.  HIP hands new streams to its four hardware
+    queues round-robin, and the step's four streams occupy all of them: a fifth stream serialises with whichever one it
+    lands on (measured: 94-127 ms per step).  So several candidates are created and each is timed against the three busy
+    streams with the 500 us spin kernel, as ops._pick_streams does; the first one that runs beside all three is kept — it
+    shares its queue with the spare side stream, which the prefix then no longer uses.  None if no candidate qualifies."""
+    import ctypes
+    import time
+    lib = ops.L.load()
+    busy = [torch.cuda.current_stream(dev), ops.side_stream(dev, 0), ops.side_stream(dev, 1)]
+
+    def run_ms(streams):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for s_ in streams:
+            if lib.stcat_spin(500, s_.cuda_stream) != 0:
+                raise ops.L.StcatHipError("stcat_spin failed")
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
+
+    single = min(run_ms(busy[:1]) for _ in range(3))
+    report = []
+    for _ in range(8):
+        out = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = lib.stcat_stream_create(PREFIX_PRIO, PREFIX_CUS, ctypes.byref(out))
+        if rc != 0 or not out.value:
+            raise ops.L.StcatHipError("stcat_stream_create failed: " + lib.stcat_last_error().decode())
+        cand = torch.cuda.ExternalStream(out.value, device=dev)
+        run_ms([cand])
+        pair = [min(run_ms([b, cand]), run_ms([b, cand])) for b in busy]
+        report.append([round(x, 3) for x in pair])
+        if all(x < 1.5 * single for x in pair):
+            PREFIX_LANE_REPORT[str(dev)] = {"spin_ms": round(single, 3), "pairs_ms": report, "picked": len(report) - 1}
+            return cand
+        torch.cuda.synchronize(dev)
+        lib.stcat_stream_destroy(out)
+    PREFIX_LANE_REPORT[str(dev)] = {"spin_ms": round(single, 3), "pairs_ms": report, "picked": None}
+    return None
+
+
+PREFIX_LANE_REPORT = {}
 
 
 def _prefix_blocks(body):
@@ -174,31 +213,55 @@ def _prefix_blocks(body):
     return out
 
 
+def _chain_cuts(n_all: int, cuda: bool):
+    """the frame ranges of the forward chains (one range = no chains)"""
+    if FORWARD_CHAINS > 1 and n_all >= 4 * FORWARD_CHAINS and cuda and ops.FORK_ENABLED:
+        k = FORWARD_CHAINS
+        cuts = [round(i * n_all / k) for i in range(k + 1)]
+        return list(zip(cuts[:-1], cuts[1:]))
+    return [(0, n_all)]
+
+
 def _prefix_forward(frames, body, out: "ops.Planes"):
     """stem + max-pool + the prefix blocks of ONE whole clip on the current stream (plane mode), the last block's output
-    (+ its ReLU bit mask when `out` carries one) written into `out`.  Same kernels, same arguments per frame as the
-    in-node path: every output element is computed by the same reduction in the same order (the chains of the in-node
-    path only cut the frame range), so the result is bit-identical to it."""
+    (+ its ReLU bit mask when `out` carries one) written into `out`.  Every conv is issued once per frame range of the
+    in-node path's forward chains (_chain_cuts), one range after the other on this stream: the SAME launches with the same
+    arguments as the in-node path (the tile / kernel picker depends on the rows of a launch, and another kernel variant
+    sums in another order), so the result is bit-identical to it (tests/test_plans.py: *_backbone_bit_exact)."""
     blks = _prefix_blocks(body)
     wp = body._wpl_cache.fwd
     s, b = body.bn1.folded()
     x = _stem(frames, body, s, b)
     x = ops.pl_maxpool_raw(x)
+    chains = _chain_cuts(x.shape[0], x.t.is_cuda)
+
+    def conv(xin, w_, s_, b_, res, stride, pad, relu, out_=None):
+        if len(chains) == 1:
+            return ops.pl_conv_fwd_raw(xin, w_, s_, b_, res, stride, pad, relu, out=(out_, None) if out_ is not None else None)[0]
+        n, H, W, _ = xin.shape
+        Cout, KH = w_.shape[0], w_.shape[1]
+        OH, OW = ops.conv_out_hw(H, W, KH, stride, pad)
+        yp = out_ if out_ is not None else ops.Planes.empty(xin.t, n, OH, OW, Cout)
+        for a, b2 in chains:
+            ops.pl_conv_fwd_raw(xin.frames(a, b2), w_, s_, b_, res.frames(a, b2) if res is not None else None, stride, pad,
+                                relu, out=(yp.frames(a, b2), None))
+        return yp
+
     for bi, blk in enumerate(blks):
         last = bi == len(blks) - 1
         w1, w2, w3 = _ohwi(blk.conv1.weight), _ohwi(blk.conv2.weight), _ohwi(blk.conv3.weight)
         s1, b1 = blk.bn1.folded()
         s2, b2 = blk.bn2.folded()
         s3, b3 = blk.bn3.folded()
-        o1, _ = ops.pl_conv_fwd_raw(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True)
-        o2, _ = ops.pl_conv_fwd_raw(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True)
+        o1 = conv(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True)
+        o2 = conv(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True)
         if blk.downsample is not None:
             wd = _ohwi(blk.downsample[0].weight)
             sd, bd = blk.downsample[1].folded()
-            idt, _ = ops.pl_conv_fwd_raw(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
+            idt = conv(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
         else:
             idt = x
-        x, _ = ops.pl_conv_fwd_raw(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, out=(out, None) if last else None)
+        x = conv(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, out_=out if last else None)
     return out
 
 
@@ -327,13 +390,10 @@ class _BackboneFnPl(Function):
         # and alternates between an MFMA-bound K loop and an HBM-bound epilogue; with two independent chains the idle
         # CUs and the idle pipe of one launch are taken by the other chain's launch.
         n_all = x.shape[0]
-        chains = [(0, n_all)]
+        chains = _chain_cuts(n_all, x.t.is_cuda)
         sides = []
-        if FORWARD_CHAINS > 1 and n_all >= 4 * FORWARD_CHAINS and x.t.is_cuda and ops.FORK_ENABLED:
-            k = FORWARD_CHAINS
-            cuts = [round(i * n_all / k) for i in range(k + 1)]
-            chains = list(zip(cuts[:-1], cuts[1:]))
-            sides = _chain_streams(x.t.device, k)
+        if len(chains) > 1:
+            sides = _chain_streams(x.t.device, len(chains))
             main = torch.cuda.current_stream(x.t.device)
 
         def conv(xin, w_, s_, b_, res, stride, pad, relu, planes_out=True, f32_out=False, want_mask=False):
@@ -495,12 +555,15 @@ class _BackboneFnPl(Function):
             # conv3 (and the downsample conv) see dz directly: their FrozenBN scale sits in the transposed weight
             # planes and in the weight-gradient epilogue
             wgrad(blk.conv3.weight, dz, o2, w3.shape, 1, 0, s3)
+            if wd is not None:
+                # (round 6: the downsample conv's weight gradient needs dz and x only — queued here, not behind conv1's:
+                #  in the LAST block of the pass, layer2.0, everything queued after the final data gradient is the step's
+                #  exposed tail: tools/tail_probe.py, 0.64 ms of the main stream waiting at the last join)
+                wgrad(blk.downsample[0].weight, dz, x, wd.shape, blk.stride, 0, sd)
             g2 = dgrad(dz, _wt(w3), o2.shape, 1, 1, 0, mask_y=o2, mask_scale=s2)
             wgrad(blk.conv2.weight, g2, o1, w2.shape, blk.stride, 1)
             g1 = dgrad(g2, _wt(w2), o1.shape, 3, blk.stride, 1, mask_y=o1, mask_scale=s1)
             wgrad(blk.conv1.weight, g1, x, w1.shape, 1, 0)
-            if wd is not None:
-                wgrad(blk.downsample[0].weight, dz, x, wd.shape, blk.stride, 0, sd)
             if sink is not None:
                 # data-parallel run: this block's weight gradients go to the gradient exchange now, from the weight-
                 # gradient stream (behind the kernels that write them), not at the end of the whole backbone backward

@@ -17,7 +17,11 @@ class DeviceFramePrefetcher:
     when they are not).  The tensor handed out stays valid until the next-but-one clip is requested (two buffers): the
     consumer's kernels of step k are ordered before the copy of clip k + 2 into the same buffer."""
 
-    def __init__(self, host_clips: Iterable[torch.Tensor], device: torch.device):
+    def __init__(self, host_clips: Iterable[torch.Tensor], device: torch.device, stage=None):
+        """stage: optional `Backbone.stage_next` (round 6) — every time a clip is handed out, the NEXT one (already
+        being copied) is declared to the backbone with its copy event, so its frozen prefix (stem + max-pool + layer1)
+        runs under the current step's grounding section"""
+        self.declare = stage
         self.it: Iterator[torch.Tensor] = iter(host_clips)
         self.dev = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
@@ -73,4 +77,6 @@ class DeviceFramePrefetcher:
         ev.record(cur)
         self.free[j] = ev
         self._issue()                               # clip k + 1 starts copying while the caller computes on clip k
+        if self.declare is not None and self._pending is not None:
+            self.declare(self.bufs[self._pending], self.ready[self._pending])
         return out

@@ -1,10 +1,13 @@
-"""Whole hot path (STCATNet forward, VideoSTGLoss, backward, PostProcess) through the C ABI vs the CPU oracle
-on identical synthetic inputs/weights.  Bars (BASELINE.json north_star): box/logit tensors within 1e-3,
-argmax temporal span bit-exact.  Gradients: 1e-3 relative to each tensor's max (fp32 chain of ~250 kernels).
+"""Whole hot path (STCATNet forward, VideoSTGLoss, backward, PostProcess) through the C ABI against the reference.
+Bars (BASELINE.json north_star): box / logit tensors within an ABSOLUTE 1e-3, argmax temporal span bit-exact, the 30 loss
+terms, and every gradient tensor held to a bound calibrated with the reference's own fp64 run (class Ref, _compare).
 
-* emulator variant (CPU, tiny clip): validates the host wiring and every kernel's index logic end to end.
-* gpu variants: C1 (T=8, 224^2) against oracle AND the committed reference goldens; C3-shaped attention at
-  T=64/448^2 is covered by tests/test_ops.py; a T=16/448^2 clip checks the full-resolution feature map here.
+* emulator variants (CPU, tiny clips, a shortened ResNet): the host wiring and every kernel's index logic end to end,
+  against the CPU oracle run here — eval mode, train mode with the kernels' own dropout masks, padded / non-square clips.
+* gpu variants: every model case of synth.MODEL_CASES at FULL size against fixtures the imported reference produced in
+  the build container (tests/golden/model_*.npz: C1, C2, C3 = the benchmark's size, C5, padded and non-square clips), the
+  benchmark's own step object replayed from its launch plans (C1, C3), and — round 6 — the TRAIN-mode step at C1 and C3
+  against fixtures computed by the oracle from the recorded dropout stream of that very step (model_C{1,3}_train.npz).
 """
 import contextlib
 import math

@@ -2,7 +2,7 @@
 # Round artifacts on the GPU box: full GPU test-suite, smoke, the bench line, rocprofv3 kernel stats, PMC HBM traffic +
 # MFMA utilisation (own passes), device timeline, host profile / phase times, step-like GEMM table, comm-mode lines.
 # Everything lands under gpurun_out/$TAG; the summaries worth judging are copied into profiles/ afterwards.
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=gpurun_out/$TAG
 mkdir -p $O
 R=$PWD
@@ -23,6 +23,10 @@ P='import json,sys; d=json.loads(sys.stdin.readline()); print({k:d.get(k) for k 
   timeout 300 $B --steps 10 --warmup 3 --no-profile --serial 2>&1 | tail -1 | python -c "$P"
   timeout 300 $B --steps 10 --warmup 3 --no-profile --hoist-loss-plan 2>&1 | tail -1 | python -c "$P"
   timeout 300 $B --steps 10 --warmup 3 --no-profile --no-auto-graph --config C1 2>&1 | tail -1 | python -c "$P"
+  echo "# round 6: --no-prefix-pipeline (every step computes its clip's frozen prefix itself) | STCAT_MHA_FP32_PIPE=1 (self-attention on the fp32-pipe kernels of round 5) | default again"
+  timeout 300 $B --steps 10 --warmup 3 --no-profile --no-prefix-pipeline 2>&1 | tail -1 | python -c "$P"
+  STCAT_MHA_FP32_PIPE=1 timeout 300 $B --steps 10 --warmup 3 --no-profile 2>&1 | tail -1 | python -c "$P"
+  timeout 300 $B --steps 10 --warmup 3 --no-profile 2>&1 | tail -1 | python -c "$P"
 } > $O/bench_variants.log 2>&1; cat $O/bench_variants.log
 # host profile of the bench mode with launch plans ON: the untraced node timeline (events between the autograd nodes of the
 # replayed step) + the per-phase table of tools/phase_times.py (default mode = the bench mode) + the Python-side profile
@@ -37,9 +41,12 @@ P='import json,sys; d=json.loads(sys.stdin.readline()); print({k:d.get(k) for k 
 } > $O/host_profile.log 2>&1; grep -A12 "phase_times" $O/host_profile.log | head -14
 timeout 300 python tools/bench_gemm.py --mma bf16x6p --step-like 2>&1 | grep -v amdgpu.ids > $O/plane_gemm_steplike.log; tail -3 $O/plane_gemm_steplike.log
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+# (round 6: --no-profile as well, so that the trace holds NOTHING but headline steps — 3 plan warm-ups (eager, eager with the
+#  staged prefix, recorded) + 1 warm-up + 3 timed = 7 identical steps; VERDICT r05 weak #9: the round-5 CSVs also held the
+#  two instrumented profiling steps of bench.py)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- $B --steps 3 --warmup 1 --no-profile > /dev/null 2>&1
 # the same command on ONE stream: per-kernel durations there are ISOLATED (nothing co-runs) — the figures `roofline` is priced on
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o bench -- $B --serial --steps 3 --warmup 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profs_$TAG -o bench -- $B --serial --steps 3 --warmup 1 --no-profile > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$TAG -o p -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$TAG -o p -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_m_$TAG -o p -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2>&1
