@@ -484,10 +484,12 @@ def main():
         step()
     fence()
     comm_events.clear()
+    pstats0 = dict(ts.model.vis_encoder[0].prefix_stats)
     t0 = time.perf_counter()
     c0 = time.process_time()
     for _ in range(args.steps):
         step()
+    pstats1 = dict(ts.model.vis_encoder[0].prefix_stats)
     host_s = time.perf_counter() - t0  # host time to ENQUEUE the steps (no sync): ~= elapsed means launch-bound
     host_cpu_s = time.process_time() - c0  # CPU time of all threads of this process while enqueuing (python + autograd
     #                                        engine thread + HIP runtime): excludes the time a full launch queue blocks
@@ -856,8 +858,9 @@ def main():
                        "prefix_pipeline": ("on: step k declares step k+1's frames (Backbone.stage_next); their frozen prefix "
                                            "(stem + max-pool + layer1, no backward: backbone.py:78-85) runs on a side stream "
                                            "under step k's grounding section; one prefix computed per step, none reused "
-                                           f"(taken {ts.model.vis_encoder[0].prefix_stats['taken']}, in place "
-                                           f"{ts.model.vis_encoder[0].prefix_stats['inline']})" if pipeline else
+                                           f"(the {args.steps} timed steps: {pstats1['taken'] - pstats0['taken']} started from a "
+                                           f"staged prefix, {pstats1['inline'] - pstats0['inline']} computed theirs in place)"
+                                           if pipeline else
                                            "off: every step computes its clip's prefix at its own head"),
                        "allreduce_bytes": reducer.message_bytes,
                        "allreduce": ({"allreduce": "all-reduce per bucket (RCCL's algorithm choice)",

@@ -634,6 +634,18 @@ class Backbone(nn.Module):
     # next step finds it, waits for its event and starts at layer2.  Nothing is cached across steps: every prefix is
     # computed once, from the frame buffer, for the one step that consumes it; a step whose frames were not staged (the
     # first step, an unmodified reference loop, evaluation) computes the prefix in place as before.
+    _TRANSIENT = {"_staged": None, "_prefix": None, "_pre_bufs": None, "_plist": None}
+
+    def __getstate__(self):
+        """copy.deepcopy / pickling (the EMA copy of scripts/train_net.py:62-64, torch.save(model)): the staging state — the
+        declared frames, the computed prefix with its HIP event, the two resident plane buffers — belongs to the running
+        loop, not to the module (an Event cannot be pickled, 2.4 GB of buffers should not be cloned into an EMA model)"""
+        st = dict(self.__dict__)
+        for k in self._TRANSIENT:
+            st[k] = {} if k == "_pre_bufs" else None
+        st["prefix_stats"] = {"staged": 0, "taken": 0, "inline": 0}
+        return st
+
     def stage_next(self, frames: torch.Tensor, ready=None) -> None:
         """declare the frames the NEXT call of the model will see (device tensor; fp32 [n,3,H,W] or uint8 [n,H,W,3]);
         `ready`: event after which they are valid (the copy stream's, loader.DeviceFramePrefetcher)"""

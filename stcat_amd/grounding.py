@@ -443,7 +443,8 @@ class QueryDecoder(plans.InvalidatesPlans, nn.Module):
         n, S, d = memory.shape
         T = frames_cls.shape[0]
         assert n == T
-        ops.run_deferred()       # (round 6: the next clip's frozen backbone prefix starts here, under the decoders' chains)
+        if PREFIX_TRIGGER == "entry":
+            ops.run_deferred()   # (round 6: the next clip's frozen backbone prefix starts here, under the decoders' chains)
         pos_query, temp_query = self.template_generator.run(frames_cls, video_cls)          # :97-99
         anchor = ops.sigmoid(pos_query)                                                      # :101
         time_embed = self.time_embed(T)[:, 0, :]                                             # :120
@@ -466,6 +467,8 @@ class QueryDecoder(plans.InvalidatesPlans, nn.Module):
         hs, ref = dec_out[0], dec_out[1]
         self.last_coord = dec_out[2] if len(dec_out) > 2 else None    # the box head, evaluated inside the decoder node
         fork.join(time_hs, weights)
+        if PREFIX_TRIGGER != "entry":
+            ops.run_deferred()   # (experiment STCAT_PREFIX_TRIGGER=exit: behind the decoders' forward, under their backward)
         return hs, ref, time_hs, weights, pos_query
 
     def forward(self, memory_cache, vis_pos=None, text_cls=None):
@@ -479,6 +482,9 @@ class QueryDecoder(plans.InvalidatesPlans, nn.Module):
                                                 memory_cache["frames_cls"], memory_cache["videos_cls"])
         # reference layouts: hs/ref/time_hs [layers, b, T, *], weights [layers, b, T, T]
         return [hs[:, None], ref[:, None]], (time_hs[:, None], weights)
+
+
+PREFIX_TRIGGER = __import__("os").environ.get("STCAT_PREFIX_TRIGGER", "entry")
 
 
 def build_encoder(cfg=None) -> CrossModalEncoder:

@@ -918,6 +918,7 @@ def _ld3(t: torch.Tensor) -> int:
 # MFMAs per wave — measured +0.25 ms per C3 step (profiles/r05_as_kernel_experiments.log, item 8); it halves the
 # attention's activation memory, which is what it is kept for.
 MHA_RECOMPUTE = bool(os.environ.get("STCAT_MHA_RECOMPUTE"))
+MHA_BS6_MIN_ROWS = int(os.environ.get("STCAT_MHA_BS6_MIN_ROWS", "128"))
 MHA_FP32_PIPE = bool(os.environ.get("STCAT_MHA_FP32_PIPE"))      # A/B switch: every mode's self-attention on the fp32-pipe kernels
 
 
@@ -947,7 +948,14 @@ class MhaSelfFn(Function):
         # bf16-pipe backward keeps a whole row's tiles in LDS and is built for S <= 256
         # (round 6: mode bf16x6p runs here too — three planes per operand, six products: csrc/attention_bs.h, NP = 3; the
         #  frozen experimental mode f16x3p keeps the fp32-pipe kernels)
-        ctx.bs = ((not need_weights) and L.get_mma_mode() not in ("f32", "f16x3p") and not MHA_FP32_PIPE
+        # In bf16x6p only rows longer than 128 tokens take the six-product kernels (the encoder's spatial layers: 207 at C3):
+        # on the decoders' 64 queries and the temporal layers' 65 rows the fp32-pipe kernels are the faster ones — forward +
+        # backward 36.0 vs 42.5 us at S = 64, 45.0 vs 48.5 at S = 65 (isolated, profiles/r06_attention.log: three planes of
+        # 256 staged rows and 97 KB of LDS per workgroup do not pay on two or three tiles) — and those launches sit on the
+        # step's latency-bound chains.
+        mode = L.get_mma_mode()
+        ctx.bs = ((not need_weights) and mode not in ("f32", "f16x3p") and not MHA_FP32_PIPE
+                  and (mode != "bf16x6p" or S > MHA_BS6_MIN_ROWS)
                   and (S <= 256 or not any(ctx.needs_input_grad[:3])))
         if ctx.bs:
             keep = any(ctx.needs_input_grad[:3])

@@ -85,3 +85,34 @@ def test_nested_tensor_contract():
     assert len(BoxList(torch.zeros(7, 4))) == 7
     with pytest.raises(ValueError):
         BoxList(torch.zeros(7, 3))
+
+
+def test_backbone_copies_without_its_staging_state():
+    """round 6: the EMA copy of the training loop (copy.deepcopy(model), scripts/train_net.py:62-64) and pickling must not
+    trip over the prefix pipeline's transient state (the declared frames, a HIP event, the resident plane buffers)"""
+    import copy
+    import pickle
+
+    import torch
+
+    from stcat_amd import backbone
+    saved = backbone.BLOCKS
+    backbone.BLOCKS = (1, 1, 1, 1)
+    try:
+        enc = backbone.build_vis_encoder(None)
+    finally:
+        backbone.BLOCKS = saved
+    bb = enc[0]
+
+    class _Unpicklable:
+        def __reduce__(self):
+            raise TypeError("cannot pickle")
+
+    bb._staged = (torch.zeros(2), 0, _Unpicklable())
+    bb._prefix = {"done": _Unpicklable(), "x": torch.zeros(3)}
+    bb._pre_bufs = {"k": [torch.zeros(10)]}
+    twin = copy.deepcopy(enc)
+    assert twin[0]._staged is None and twin[0]._prefix is None and twin[0]._pre_bufs == {}
+    assert bb._prefix is not None and bb._staged is not None                  # the original keeps running
+    assert [n for n, _ in twin.named_parameters()] == [n for n, _ in enc.named_parameters()]
+    pickle.dumps(enc)

@@ -844,6 +844,8 @@ def _mha_bs_six_products(dev, big):
     fp32 PyTorch reference with the fp32 kernels' tolerance (TOL), and — what tells six products from three — much closer to
     an fp64 evaluation than the three-product kernel is."""
     L.set_mma_mode("bf16x6p")
+    saved_min = ops.MHA_BS6_MIN_ROWS
+    ops.MHA_BS6_MIN_ROWS = 0       # (the model routes rows of <= 128 tokens to the fp32-pipe kernels: here every shape runs NP = 3)
     try:
         _mha_case(dev, 2, 37, 2, need_w=False, packed=True, masked=True)       # two key tiles, ragged
         _mha_case(dev, 1, 65, 1, need_w=False, packed=False, masked=True)      # temporal-layer shape (T + 1)
@@ -874,6 +876,7 @@ def _mha_bs_six_products(dev, big):
             _mha_case(dev, 2, 256, 8, need_w=False, packed=True, masked=False)
             _mha_dropout_case(dev, 4, 207, 8, need_w=False, pdrop=0.1)
     finally:
+        ops.MHA_BS6_MIN_ROWS = saved_min
         L.set_mma_mode("f32")
 
 
