@@ -832,6 +832,7 @@ def main():
             "host_note": "host_enqueue_ms_per_step is wall time of the enqueue loop: it INCLUDES the time hipLaunchKernel "
                          "blocks while the launch queue is full (the host runs ahead of a GPU-bound step); the host's own "
                          "work is the C1 line of profiles/r03_bench_variants.log (same launch sequence, ~no GPU work)",
+            "plan_stats": dict(plans.STATS),
             "streams": ops.PICK_REPORT.get(str(dev)),
             "prefix_lane": __import__("stcat_amd.backbone", fromlist=["x"]).PREFIX_LANE_REPORT.get(str(dev)),
             "exposed_comm_ms_per_step": (round(exposed_ms, 3) if exposed_ms is not None else None),

@@ -224,7 +224,17 @@ class Recorder:
         self.yields.append((fn, stream))
         if self.lib.stcat_plan_add_yield(self.h, len(self.yields) - 1) != 0:
             raise L.StcatHipError(self.lib.stcat_last_error().decode())
-        return fn()
+        # The action is host code by definition — bucket copies, the asynchronous all-reduce of a completed bucket
+        # (c10d.allreduce_) — and runs again at this point of every replay: the dispatch watch must not count its kernels
+        # as "foreign kernels of the node body".  (Round 6: it did, so with a live process group the backbone's backward
+        # recording was REFUSED and the whole backbone node stayed on the eager path: +6 ms of host enqueue each way and
+        # +3.4 ms per step at one rank, profiles/r06_prefix_pipeline.log — every N > 1 run since the watch became
+        # unconditional in round 4 carried that.)
+        prev, self.allow_foreign = self.allow_foreign, True
+        try:
+            return fn()
+        finally:
+            self.allow_foreign = prev
 
     def effect(self, fn) -> None:
         """a host-side state change of the region (dropout bookkeeping): repeated after every replay"""

@@ -82,6 +82,7 @@ def test_bench_default_line_over_the_rccl_path_single_rank():
     assert d["exposed_comm_ms_per_step"] is not None and d["exposed_comm_ms_per_step"] >= 0
     assert d["dtype"].startswith("f32-class") and "launch_modes" not in d
     assert d["config"]["launch"].startswith("launch plans")      # round 3: composite nodes replayed by one C call each
+    assert not d["plan_stats"].get("refused"), d["plan_stats"]   # round 6: no node falls back to eager under a live group
     assert d["config"]["loss_plan"].startswith("rebuilt inside every timed step")
     assert d["throughput_mode"]["mma"].startswith("3 bf16 cross terms") and d["throughput_mode"]["steps"] == 10
     assert d["exact_f32_mode"]["steps"] == 10 and d["exact_f32_mode"]["warmup"] == 3

@@ -230,6 +230,58 @@ def test_emu_recording_refuses_a_node_that_runs_foreign_kernels():
         plans.clear()
 
 
+class _NodeWithHostCall(torch.autograd.Function):
+    """a node whose backward hands its weight gradient to the host in mid-sequence (ops.host_call: what the backbone's
+    backward does for the data-parallel reducer) — the host action runs aten kernels (a bucket copy, an all-reduce)"""
+    LOG = []
+    BUCKET = None
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.ew(_lib.EW_MUL, x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        gw = ops.ew(_lib.EW_MUL, dy, x)
+
+        def deliver():
+            _NodeWithHostCall.BUCKET.copy_(gw)            # an aten kernel, on purpose
+            _NodeWithHostCall.LOG.append(float(_NodeWithHostCall.BUCKET.sum()))
+            return True
+        ops.host_call(deliver)
+        return ops.ew(_lib.EW_MUL, dy, w), gw
+
+
+def test_emu_host_call_inside_a_recording_is_not_a_foreign_kernel():
+    """round 6: with a live process group the reducer's early hand-over (a plan YIELD) launches the all-reduce of a
+    completed bucket — an aten / c10d op — from inside the backbone's backward.  The dispatch watch counted it as a
+    foreign kernel of the node body and refused the plan: the backbone stayed eager in every N > 1 run.  A host call's
+    kernels are the host's: the node is recorded, and the action runs again at that point of every replay."""
+    dev = use_emu()
+    plans.clear()
+    plans.enable(True)
+    plans.STATS.update(recorded=0, replayed=0, eager=0, run_s=0.0, refused=0)
+    _NodeWithHostCall.LOG.clear()
+    _NodeWithHostCall.BUCKET = torch.zeros(3, 4)
+    try:
+        w = torch.nn.Parameter(torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1.0)
+        for k in range(4):
+            x = (torch.arange(12, dtype=torch.float32).reshape(3, 4) * (k + 1)).requires_grad_(True) * 1.0
+            w.grad = None
+            y = plans.apply(_NodeWithHostCall, x, w)
+            y.sum().backward()
+            assert torch.equal(w.grad, x.detach()), k
+            assert torch.equal(_NodeWithHostCall.BUCKET, x.detach()), k          # delivered at every call, replays included
+        assert len(_NodeWithHostCall.LOG) == 4
+        assert not plans.STATS.get("refused") and plans.STATS["recorded"] == 2 and plans.STATS["replayed"] == 4, plans.STATS
+    finally:
+        plans.enable(False)
+        plans.clear()
+
+
 class _LinearNode(torch.autograd.Function):
     """y = x w^T + b with the composite layers' own backward (`composite._lin_b`): rows > 256 take the data gradient
     through the CACHED transposed weight (ops.LinearTransposes.get)"""

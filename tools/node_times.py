@@ -25,13 +25,22 @@ ap.add_argument("--config", default="C3")
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--eager", action="store_true", help="launch plans off")
 ap.add_argument("--no-prefix-pipeline", action="store_true", help="every step computes its clip's frozen prefix itself")
+ap.add_argument("--force-comm", action="store_true", help="the complete RCCL path with ONE rank (bench.py's STCAT_FORCE_COMM=1)")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
 _lib.load()
 _lib.set_mma_mode(args.mma)
 plans.enable(not args.eager)
-ts = TrainStep(dev, args.config, pipeline_prefix=not args.no_prefix_pipeline)
+if args.force_comm:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    from stcat_amd.dist import init_rccl_process_group
+    init_rccl_process_group(dev)
+ts = TrainStep(dev, args.config, pipeline_prefix=not args.no_prefix_pipeline, force_comm=args.force_comm)
 marks = []
 ON = [False]
 
