@@ -34,5 +34,10 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 1))[0]
     out[name] = {"launches": fn, "read_MB_per_launch": round(2 * fs * 1024 / max(fn, 1) / 1e6, 3),
                  "write_MB_per_launch": round(ws * 1024 / max(wn, 1) / 1e6, 3)}
 from bench import source_sha  # noqa: E402
-steps = sum(v["launches"] for k, v in out.items() if "igemm_stem_kernel" in k or "stem_pl_kernel" in k)     # one stem launch per forward pass
+# steps of the traced command: one loss-forward launch per step.  (Round 5 counted stem launches; with the pipelined prefix a
+# process launches steps + 1 stems — the first step computes its own prefix and stages the next one's, the last step stages
+# one that nobody consumes — and the per-step figures came out a sixth too small in a 5-step pass.)
+steps = sum(v["launches"] for k, v in out.items() if "stg_loss_fwd_kernel" in k)
+if not steps:
+    steps = sum(v["launches"] for k, v in out.items() if "igemm_stem_kernel" in k or "stem_pl_kernel" in k)
 print(json.dumps({"source_sha": source_sha(), "steps_traced": steps, "note": "FETCH_SIZE x1024 x2 (gfx950 correction), WRITE_SIZE x1024; per launch", "kernels": out}))
