@@ -312,9 +312,13 @@ int stcat_mha_self_bwd_lse(const float* q, const float* k, const float* v, const
                            const float* dout, const float* lse, float* dq, float* dk, float* dv, int B, int H, int S,
                            int ldq, int ldk, int ldv, int ldo, int ldg, int ldgv, float scale, float drop_p,
                            long drop_seed, long drop_offset, const long* drop_base, void* stream);
-/* The same core on the bf16 matrix pipe (split-bf16 x3 products, fp32 accumulate) with an online softmax: any S,
- * nothing but the row log-sum-exp lse[B,H,S] kept for backward (no probability stash); no head-mean weights.
- * stcat_mha_bs_bwd recomputes the probabilities from q, k and lse and produces dq, dk, dv in ONE launch (S <= 256).
+/* The same core on the bf16 matrix pipe (fp32 accumulate) with an online softmax: any S, nothing but the row
+ * log-sum-exp lse[B,H,S] kept for backward (no probability stash); no head-mean weights.  The arithmetic follows the
+ * mma mode: two bf16 planes per operand and three products (modes bf16x3 / bf16x6 / bf16x3p), or — mode bf16x6p,
+ * round 6 — THREE planes per operand (their sum is the fp32 value) and the six cross terms of the plane GEMMs, also
+ * for the probabilities and dS that feed the second contraction.  stcat_mha_bs_bwd recomputes the probabilities from
+ * q, k and lse (S <= 256): ONE launch for two planes; for three planes two launches (dQ with K / V planes in LDS, dK / dV
+ * with Q / dO planes in LDS: all four as three planes would be 172 KB at S = 224).
  * Replaces nn.MultiheadAttention's core in modal_encoder.py:161-168, 180-185, 228-242 and query_decoder.py:341. */
 int stcat_mha_bs_fwd(const float* q, const float* k, const float* v, const unsigned char* kpm, float* o, float* lse,
                      int B, int H, int S, int ldq, int ldk, int ldv, int ldo, float scale, float drop_p, long drop_seed,
