@@ -477,8 +477,9 @@ def main():
         # a node runs eagerly the first time it sees a signature and is recorded the second time: both happen here, so
         # the W warm-up steps and the K timed steps are all replays, whatever W is
         # (with the pipelined prefix the backbone node has two signatures: the first step computes its prefix in place,
-        #  the following ones find it staged — eager, eager + staged, record, then replays)
-        for _ in range(3 if pipeline else 2):
+        #  the following ones find it staged — eager, eager + staged, record, then replays; the staged prefix itself is a
+        #  launch plan per resident buffer, and the two buffers alternate: eager, eager, record, record — five steps)
+        for _ in range(5 if pipeline else 2):
             step()
     for _ in range(args.warmup):
         step()

@@ -34,6 +34,18 @@ PREFIX_PIPELINE = not os.environ.get("STCAT_NO_PREFIX_PIPELINE")
 PREFIX_STREAM = int(os.environ.get("STCAT_PREFIX_STREAM", "2"))     # index into ops.side_stream (2 = the spare queue)
 PREFIX_PRIO = int(os.environ.get("STCAT_PREFIX_PRIO", "0"))         # 0 = a measured-concurrent default-priority side stream; 1 = least priority
 PREFIX_CUS = int(os.environ.get("STCAT_PREFIX_CUS", "0"))           # > 0: the prefix stream is masked to this many CUs
+# the prefix blocks' convs in pieces of this many frames (0 = the forward chains' own ranges).  Default "auto": 4 frames on a
+# single GPU, 0 under a live gradient exchange — measured both ways on one box (profiles/r06_prefix_pipeline.log): pieces of
+# 4 gain 0.65 ms per step without a process group and LOSE 0.8 ms with one (the longer-lived prefix then also shares the
+# chip with the reducer's copies and collectives)
+_PREFIX_RANGE_ENV = os.environ.get("STCAT_PREFIX_RANGE", "auto")
+
+
+def _prefix_range() -> int:
+    if _PREFIX_RANGE_ENV != "auto":
+        return int(_PREFIX_RANGE_ENV)
+    sink = ops.GRAD_SINK
+    return 0 if (sink is not None and getattr(sink, "comm", False)) else 4
 PREFIX_AT = os.environ.get("STCAT_PREFIX_AT", "decoder")             # "decoder": queued at the query decoder's entry; "backbone"
 
 
@@ -222,6 +234,24 @@ def _chain_cuts(n_all: int, cuda: bool):
     return [(0, n_all)]
 
 
+def _prefix_ranges(chains):
+    """the frame ranges the PREFIX blocks' convs are issued on: each forward chain's range cut into pieces of at most
+    _prefix_range() frames (0 = the chains' own ranges).  A launch over few frames has fewer workgroups than the chip has CUs
+    (4 frames of layer1 at 448 x 448 are 196 tiles of 256 rows), and the launches of one stream run one after the other:
+    the background prefix then never holds more than ~3/4 of the chip, and the decoders' dependent small launches beside it
+    — whose workgroups need a CU that a plane-GEMM workgroup has vacated entirely (it owns the CU's registers and LDS) —
+    always find free ones.  The in-step path uses the same pieces (bit-identical results: the tile / kernel picker depends
+    on a launch's rows)."""
+    step = _prefix_range()
+    if step <= 0:
+        return [(a, b, ci) for ci, (a, b) in enumerate(chains)]
+    out = []
+    for ci, (a, b) in enumerate(chains):
+        for lo in range(a, b, step):
+            out.append((lo, min(b, lo + step), ci))
+    return out
+
+
 def _prefix_forward(frames, body, out: "ops.Planes"):
     """stem + max-pool + the prefix blocks of ONE whole clip on the current stream (plane mode), the last block's output
     (+ its ReLU bit mask when `out` carries one) written into `out`.  Every conv is issued once per frame range of the
@@ -233,7 +263,7 @@ def _prefix_forward(frames, body, out: "ops.Planes"):
     s, b = body.bn1.folded()
     x = _stem(frames, body, s, b)
     x = ops.pl_maxpool_raw(x)
-    chains = _chain_cuts(x.shape[0], x.t.is_cuda)
+    chains = [(a, b) for a, b, _ in _prefix_ranges(_chain_cuts(x.shape[0], x.t.is_cuda))]
 
     def conv(xin, w_, s_, b_, res, stride, pad, relu, out_=None):
         if len(chains) == 1:
@@ -396,8 +426,13 @@ class _BackboneFnPl(Function):
             sides = _chain_streams(x.t.device, len(chains))
             main = torch.cuda.current_stream(x.t.device)
 
-        def conv(xin, w_, s_, b_, res, stride, pad, relu, planes_out=True, f32_out=False, want_mask=False):
-            if not sides:
+        n_prefix_blocks = len(_prefix_blocks(body))
+        pieces_pre = _prefix_ranges(chains)
+        pieces_all = [(a, b, ci) for ci, (a, b) in enumerate(chains)]
+
+        def conv(xin, w_, s_, b_, res, stride, pad, relu, planes_out=True, f32_out=False, want_mask=False, prefix=False):
+            pieces = pieces_pre if prefix else pieces_all
+            if not sides and len(pieces) == 1:
                 return ops.pl_conv_fwd_raw(xin, w_, s_, b_, res, stride, pad, relu, planes_out=planes_out, f32_out=f32_out,
                                            want_mask=want_mask)
             n, H, W, _ = xin.shape
@@ -413,10 +448,10 @@ class _BackboneFnPl(Function):
                         t_.record_stream(sd_)
                     if ops.L.RECORDER is not None:
                         ops.L.RECORDER.keep.append(t_)
-            for ci, (a, b) in enumerate(chains):
+            for a, b, ci in pieces:
                 o = (yp.frames(a, b) if yp is not None else None, yf_[a:b] if yf_ is not None else None)
                 args = (xin.frames(a, b), w_, s_, b_, res.frames(a, b) if res is not None else None, stride, pad, relu)
-                if ci == 0:
+                if ci == 0 or not sides:
                     ops.pl_conv_fwd_raw(*args, out=o)
                 else:
                     with torch.cuda.stream(sides[ci - 1]):
@@ -446,17 +481,18 @@ class _BackboneFnPl(Function):
             # consumer (the next block) is trainable
             tr = need_bwd and blk.conv1.weight.requires_grad
             tr_next = need_bwd and not last and blocks[bi + 1][1].conv1.weight.requires_grad
-            o1, _ = conv(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True, want_mask=tr)
-            o2, _ = conv(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True, want_mask=tr)
+            pre_ = bi < n_prefix_blocks       # a frozen prefix block computed in the step: the staged path's pieces
+            o1, _ = conv(x, wp[w1.data_ptr()], s1, b1, None, 1, 0, True, want_mask=tr, prefix=pre_)
+            o2, _ = conv(o1, wp[w2.data_ptr()], s2, b2, None, blk.stride, 1, True, want_mask=tr, prefix=pre_)
             wd = sd = None
             if blk.downsample is not None:
                 wd = _ohwi(blk.downsample[0].weight)
                 sd, bd = blk.downsample[1].folded()
-                idt, _ = conv(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False)
+                idt, _ = conv(x, wp[wd.data_ptr()], sd, bd, None, blk.stride, 0, False, prefix=pre_)
             else:
                 idt = x
             y, yf = conv(o2, wp[w3.data_ptr()], s3, b3, idt, 1, 0, True, planes_out=not last, f32_out=last,
-                         want_mask=tr_next)
+                         want_mask=tr_next, prefix=pre_)
             if need_bwd and blk.conv1.weight.requires_grad:
                 # (the LAST block's output is this node's own output: the tape keeps a detached alias of it — the output
                 #  object itself would close a reference cycle through its grad_fn that only backward() ever opened, and a
@@ -621,6 +657,7 @@ class Backbone(nn.Module):
         self._staged = None      # (frames, version, ready event) of the clip the NEXT step will run (stage_next)
         self._prefix = None      # the frozen prefix computed for it: dict(frames, version, x, done, stream)
         self._pre_bufs = {}      # (shape, dtype, planes) -> two output plane sets, used alternately
+        self._pre_plans = {}     # launch plans of the staged prefix, one per (geometry, buffer slot)
         self._pre_slot = 0
         self.prefix_stats = {"staged": 0, "taken": 0, "inline": 0}
 
@@ -634,7 +671,7 @@ class Backbone(nn.Module):
     # next step finds it, waits for its event and starts at layer2.  Nothing is cached across steps: every prefix is
     # computed once, from the frame buffer, for the one step that consumes it; a step whose frames were not staged (the
     # first step, an unmodified reference loop, evaluation) computes the prefix in place as before.
-    _TRANSIENT = {"_staged": None, "_prefix": None, "_pre_bufs": None, "_plist": None}
+    _TRANSIENT = {"_staged": None, "_prefix": None, "_pre_bufs": None, "_plist": None, "_pre_plans": None}
 
     def __getstate__(self):
         """copy.deepcopy / pickling (the EMA copy of scripts/train_net.py:62-64, torch.save(model)): the staging state — the
@@ -642,7 +679,7 @@ class Backbone(nn.Module):
         loop, not to the module (an Event cannot be pickled, 2.4 GB of buffers should not be cloned into an EMA model)"""
         st = dict(self.__dict__)
         for k in self._TRANSIENT:
-            st[k] = {} if k == "_pre_bufs" else None
+            st[k] = {} if k in ("_pre_bufs", "_pre_plans") else None
         st["prefix_stats"] = {"staged": 0, "taken": 0, "inline": 0}
         return st
 
@@ -678,6 +715,7 @@ class Backbone(nn.Module):
         main = torch.cuda.current_stream(dev) if cuda else None
         if bufs is None:
             self._pre_bufs.clear()           # (one clip geometry at a time: 1.2 GB per buffer at C3)
+            self._pre_plans.clear()
             bufs = []
             for _ in range(2):
                 pl = ops.Planes.empty(frames, n, OH, OW, C)
@@ -697,25 +735,54 @@ class Backbone(nn.Module):
                 side = None
         with torch.no_grad():
             if side is None:
-                _prefix_forward(frames, self.body, out)
+                self._run_prefix(frames, out, key)
                 done = None
             else:
                 side.wait_stream(main)               # behind the current clip's forward (and the weight-plane refresh)
                 if ready is not None:
                     side.wait_event(ready)
                 with torch.cuda.stream(side):        # (its temporaries belong to the side stream's pool)
-                    _prefix_forward(frames, self.body, out)
+                    self._run_prefix(frames, out, key)
                     done = torch.cuda.Event()
                     done.record(side)
                 frames.record_stream(side)
         self._prefix = {"frames": frames, "version": ver, "x": out, "done": done, "want_mask": want_mask,
                         "state": self._prefix_state()}
 
+    def _run_prefix(self, frames, out, key) -> None:
+        """the staged prefix's launches on the current stream: eagerly the first time a (geometry, buffer slot) is seen,
+        recorded into a launch plan the second time, replayed by ONE C call afterwards (its 22 — or, in pieces of
+        _prefix_range() frames, ~170 — launches otherwise cost the host thread 0.5 — 4 ms per step, which shows as soon as
+        the host is busy: with a live process group the step is nearly host-bound).  The plan's only external tensor is
+        the frame buffer; its output planes are the resident buffer of this slot, its temporaries live in its own pool."""
+        if not plans.ENABLED or ops.L.RECORDER is not None or frames.device.type != "cuda":
+            _prefix_forward(frames, self.body, out)
+            return
+        pk = (key, self._pre_slot, tuple(frames.shape), frames.dtype, frames.data_ptr() % 16, self._prefix_state())
+        if not any(c is self._pre_plans for c in plans._CACHES):
+            plans._CACHES.append(self._pre_plans)        # (plans.clear() drops these with every other plan)
+        ent = self._pre_plans.get(pk)
+        if ent is None:
+            if len(self._pre_plans) >= 8:
+                self._pre_plans.clear()
+            ent = self._pre_plans[pk] = {"calls": 0, "plan": None, "pool": None, "refused": False}
+        ent["calls"] += 1
+        if ent["calls"] == 1 or ent["refused"]:
+            _prefix_forward(frames, self.body, out)
+        elif ent["plan"] is None:
+            ent["pool"] = torch.cuda.MemPool()
+            _, plan = plans._record(frames.device, [frames], ent["pool"], lambda: _prefix_forward(frames, self.body, out))
+            if plan is None:
+                ent["refused"] = True
+            ent["plan"] = plan
+        else:
+            ent["plan"].run([frames])
+
     def _prefix_state(self):
         """what a computed prefix depends on besides the frames: the arithmetic mode (plane count AND element type), the
         static tables (FrozenBN folds / weight planes: plans.STATIC_EPOCH moves with load_state_dict / .to()) and how many
         blocks are frozen"""
-        return (ops.L.get_mma_mode(), ops.L.plane_count(), plans.STATIC_EPOCH, len(_prefix_blocks(self.body)))
+        return (ops.L.get_mma_mode(), ops.L.plane_count(), plans.STATIC_EPOCH, len(_prefix_blocks(self.body)), _prefix_range())
 
     def _take(self, frames: torch.Tensor):
         """the prefix computed for exactly these frames, or None; the current stream is ordered behind it"""
