@@ -46,6 +46,7 @@ def _prefix_range() -> int:
         return int(_PREFIX_RANGE_ENV)
     sink = ops.GRAD_SINK
     return 0 if (sink is not None and getattr(sink, "comm", False)) else 4
+PREFIX_EAGER = bool(os.environ.get("STCAT_PREFIX_EAGER"))           # the staged prefix launch by launch (no launch plan)
 PREFIX_AT = os.environ.get("STCAT_PREFIX_AT", "decoder")             # "decoder": queued at the query decoder's entry; "backbone"
 
 
@@ -755,7 +756,7 @@ class Backbone(nn.Module):
         _prefix_range() frames, ~170 — launches otherwise cost the host thread 0.5 — 4 ms per step, which shows as soon as
         the host is busy: with a live process group the step is nearly host-bound).  The plan's only external tensor is
         the frame buffer; its output planes are the resident buffer of this slot, its temporaries live in its own pool."""
-        if not plans.ENABLED or ops.L.RECORDER is not None or frames.device.type != "cuda":
+        if not plans.ENABLED or ops.L.RECORDER is not None or frames.device.type != "cuda" or PREFIX_EAGER:
             _prefix_forward(frames, self.body, out)
             return
         pk = (key, self._pre_slot, tuple(frames.shape), frames.dtype, frames.data_ptr() % 16, self._prefix_state())

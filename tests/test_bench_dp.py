@@ -85,7 +85,7 @@ def test_bench_default_line_over_the_rccl_path_single_rank():
     assert not d["plan_stats"].get("refused"), d["plan_stats"]   # round 6: no node falls back to eager under a live group
     assert d["config"]["loss_plan"].startswith("rebuilt inside every timed step")
     assert d["throughput_mode"]["mma"].startswith("3 bf16 cross terms") and d["throughput_mode"]["steps"] == 10
-    assert d["exact_f32_mode"]["steps"] == 10 and d["exact_f32_mode"]["warmup"] == 3
+    assert d["exact_f32_mode"]["steps"] == 10 and d["exact_f32_mode"]["warmup"] == 5   # (five with the pipelined prefix)
     # round 4: the experimental 22-bit mode (two fp16 planes) is timed beside the headline, never in its place
     assert d["near_f32_mode"]["mma"].startswith("3 fp16 cross terms") and d["near_f32_mode"]["steps"] == 10
     assert d["kernels"]["stcat_weight_planes_multi"]["launches"] == 1

@@ -741,7 +741,11 @@ def _run_bench_step(dev, name, mma, steps=3, train=False, use_plans=True, zero_d
         if use_plans:
             # the last step replayed every composite node, forward and backward: nothing ran eager, nothing was recorded
             assert plans.STATS["replayed"] - before["replayed"] >= 8, (before, plans.STATS)
-            assert plans.STATS["recorded"] == before["recorded"] and plans.STATS["eager"] == before["eager"], (before, plans.STATS)
+            # (pipeline: the staged prefix is a launch plan per resident buffer — eager, eager, recorded, recorded over the
+            #  four steps — so the LAST step records the second buffer's plan: a real execution, queued for the step after
+            #  it; the composite nodes of the step under test are all replays)
+            assert plans.STATS["recorded"] - before["recorded"] <= (1 if pipeline else 0), (before, plans.STATS)
+            assert plans.STATS["eager"] == before["eager"], (before, plans.STATS)
             assert not plans.STATS.get("refused"), plans.STATS
         keep = {k: v.cpu() for k, v in ts.last_out.items() if torch.is_tensor(v)}
         keep["aux"] = [{k: v.cpu() for k, v in a.items()} for a in ts.last_out["aux"]]
