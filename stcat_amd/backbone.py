@@ -296,6 +296,14 @@ def _prefix_forward(frames, body, out: "ops.Planes"):
     return out
 
 
+def _backward_done(body) -> None:
+    """the backbone node's backward has run (also replayed as a plan effect): the resident prefix buffer that forward read
+    may be written again — see Backbone.features_nhwc"""
+    body._bwd_pending = False
+    if ops.L.RECORDER is not None:
+        ops.L.RECORDER.effect(lambda: setattr(body, "_bwd_pending", False))
+
+
 class _BackboneFn(Function):
     """frames [n,3,H,W] (NCHW, as handed over by the data pipeline) -> layer4 features NHWC [n,H/32,W/32,2048]."""
 
@@ -637,6 +645,7 @@ class _BackboneFnPl(Function):
             ctx.tape = None
             ctx.wt = None
         ops.dropout_backward_done()
+        _backward_done(ctx.body)
         return (None, None, None, None, *out)
 
 
@@ -715,6 +724,8 @@ class Backbone(nn.Module):
         bufs = self._pre_bufs.get(key)
         main = torch.cuda.current_stream(dev) if cuda else None
         if bufs is None:
+            if cuda and self._pre_bufs and str(dev) in _PREFIX_LANES:
+                main.wait_stream(_PREFIX_LANES[str(dev)])     # (a prefix of the old geometry may still be running on its lane)
             self._pre_bufs.clear()           # (one clip geometry at a time: 1.2 GB per buffer at C3)
             self._pre_plans.clear()
             bufs = []
@@ -814,6 +825,16 @@ class Backbone(nn.Module):
             need_mask = torch.is_grad_enabled() and any(w.requires_grad for w in weights)
             if pre is not None and need_mask and pre.mask is None:
                 pre = None
+            # Two resident buffers alternate: this forward reads one (its backward too: layer2.0's weight gradients), the
+            # prefix staged during this forward fills the other.  That is only safe when the PREVIOUS forward's backward
+            # has run — with two forwards before a backward (gradient accumulation over two clips) the staged prefix
+            # would overwrite the buffer the earlier forward's backward still needs: no staging in such a pass (the next
+            # step computes its prefix in place).  A forward that is never back-propagated costs one skipped staging.
+            if need_mask:
+                if getattr(self.body, "_bwd_pending", False) and self._staged is not None:
+                    self._staged = None
+                    self.prefix_stats["skipped_busy"] = self.prefix_stats.get("skipped_busy", 0) + 1
+                self.body._bwd_pending = True
             self.prefix_stats["taken" if pre is not None else "inline"] += 1
             feat = plans.apply(_BackboneFnPl, frames, self.body, pre.t if pre is not None else None,
                                pre.mask if pre is not None else None, *weights)

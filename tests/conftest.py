@@ -33,7 +33,7 @@ _GPU_ORDER = ("test_library.py", "test_ops.py", "test_map2d.py", "test_model_par
 
 
 # the CPU selection is distributed over workers: its longest tests start first (longest-processing-time order)
-_CPU_SLOW_FIRST = ("test_emu_plans_replay", "test_emu_prefix_pipeline_backbone", "test_emu_prefix_pipeline_equals", "test_emu_train_mode_dropout", "test_emu_two_forwards", "test_emu_tiny_clip_bf16x6_planes",
+_CPU_SLOW_FIRST = ("test_emu_plans_replay", "test_emu_prefix_pipeline_backbone", "test_emu_prefix_pipeline_equals", "test_emu_prefix_pipeline_two_forwards", "test_emu_train_mode_dropout", "test_emu_two_forwards", "test_emu_tiny_clip_bf16x6_planes",
                    "test_emu_nonsquare", "test_emu_train_mode_against_oracle", "test_oracle_against_model_fixture",
                    "test_emu_tiny_clip", "test_install_is_a_drop_in", "test_emu_pl_conv", "test_emu_map2d", "test_loss_and_grads")
 

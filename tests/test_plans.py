@@ -546,6 +546,78 @@ def test_emu_prefix_pipeline_backbone_bit_exact():
     _prefix_pipeline_backbone_bit_exact(use_emu(), 2, 32, (1, 1, 2, 1))
 
 
+def _prefix_pipeline_two_forwards_before_backward(dev, T, res, blocks):
+    """gradient accumulation over two clips: forward A, forward B, then both backward passes.  B's forward must NOT stage a
+    prefix (it would fill the resident buffer A's backward still reads — layer2.0's weight gradients); every gradient equals
+    the one-forward-one-backward reference, bit for bit."""
+    from stcat_amd import backbone
+    _lib.set_mma_mode("bf16x6p")
+    saved = backbone.BLOCKS
+    if blocks is not None:
+        backbone.BLOCKS = blocks
+    try:
+        enc = backbone.build_vis_encoder(None)
+    finally:
+        backbone.BLOCKS = saved
+    try:
+        synth.fill_module_(enc)
+        enc.to(dev)
+        bb = enc[0]
+        g = torch.Generator().manual_seed(5)
+        A, B, C = (torch.randn(T, 3, res, res, generator=g).to(dev) for _ in range(3))
+        gy = torch.randn(T, res // 32, res // 32, 2048, generator=g).to(dev)
+        plans.clear()
+        plans.enable(False)
+
+        def grads_of(frames):
+            for p in bb.parameters():
+                p.grad = None
+            f = bb.features_nhwc(frames)
+            ops.run_deferred()
+            f.backward(gy)
+            return {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+
+        ref_a, ref_b = grads_of(A), grads_of(B)
+        # pipelined: a warm step on C stages A; then A (takes its prefix, stages B), B (takes its prefix; staging C is refused:
+        # A's backward is outstanding), backward of B, backward of A
+        bb.stage_next(A)
+        grads_of(C)
+        for p in bb.parameters():
+            p.grad = None
+        bb.stage_next(B)
+        fa = bb.features_nhwc(A)
+        ops.run_deferred()
+        bb.stage_next(C)
+        fb = bb.features_nhwc(B)
+        ops.run_deferred()
+        assert bb.prefix_stats.get("skipped_busy") == 1 and bb._prefix is None, bb.prefix_stats
+        fb.backward(gy)
+        gb = {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+        for p in bb.parameters():
+            p.grad = None
+        fa.backward(gy)
+        ga = {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None}
+        assert all(torch.equal(ga[n], ref_a[n]) for n in ref_a) and all(torch.equal(gb[n], ref_b[n]) for n in ref_b)
+        # and the step after that stages again
+        bb.stage_next(A)
+        grads_of(C)
+        assert bb._prefix is not None
+    finally:
+        plans.enable(False)
+        plans.clear()
+        _lib.set_mma_mode("f32")
+
+
+def test_emu_prefix_pipeline_two_forwards_before_backward():
+    _prefix_pipeline_two_forwards_before_backward(use_emu(), 2, 32, (1, 1, 2, 1))
+
+
+@pytest.mark.gpu
+def test_gpu_prefix_pipeline_two_forwards_before_backward():
+    from tests.backends import use_hip
+    _prefix_pipeline_two_forwards_before_backward(use_hip(), 8, 224, None)
+
+
 @pytest.mark.gpu
 def test_gpu_prefix_pipeline_backbone_bit_exact():
     """the full ResNet-101 at T = 8, 224 x 224: the staged prefix issues each conv once per frame range of the forward chains,
