@@ -703,7 +703,8 @@ class Backbone(nn.Module):
         self.prefix_stats["staged"] += 1
 
     def _fill(self) -> None:
-        """called once the current clip's forward has been queued (Joiner.forward_tokens): queue the staged clip's prefix"""
+        """called once the current clip's forward has been queued — from the query decoder's entry (ops.run_deferred) or, with
+        STCAT_PREFIX_AT=backbone, right behind the backbone node: queue the staged clip's prefix on its lane"""
         st, self._staged = self._staged, None
         if st is None or not ops.L.plane_count() or not _prefix_blocks(self.body):
             return
