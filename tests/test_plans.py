@@ -418,10 +418,6 @@ def _prefix_pipeline_case(dev, T, res, steps, train, tol, grad_l2):
                 if train:
                     ops.dropout_begin_step(dev)
                 cur, nxt = clips[k % 2], clips[(k + 1) % 2]
-                if k == 3:
-                    # the third visit of clip B sees NEW pixels in the same buffer: written before it is declared below (a
-                    # rewrite AFTER the declaration is caught by the version check: covered at k == 4)
-                    pass
                 if mode == "pipelined":
                     bb.stage_next(nxt.tensors)
                 res_.append(_step(model, criterion, wd, cur, T, res, dev))
