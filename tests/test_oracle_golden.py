@@ -194,3 +194,27 @@ def test_oracle_against_model_fixture(golden_dir, name):
             # thread partitions) differ by ReLU-kink flips: as far apart as the fp32 reference is from its fp64 run
             # (C1: layer2 / layer3 tensors 1e-2 .. 3e-2) — the fp64 comparison above is the sharp one
             assert errs[len(errs) // 2] <= 1e-5 and errs[-1] <= 2e-1, (name, errs[len(errs) // 2], errs[-5:])   # (8 threads: 4.8e-3; 2 threads: 7.8e-2)
+
+
+def test_train_mode_fixture_is_the_oracle_with_the_recorded_dropout_stream(golden_dir):
+    """Round 6: tests/golden/model_C1_train.npz (and its C3 sibling, same recipe) holds what the ORACLE gives for the
+    benchmark's train-mode step when every dropout site draws the masks of the stream recorded on the GPU — seed, device
+    base and (offset, size) per site, stored inside the fixture.  Re-derived here from that stream alone: the host twin of
+    csrc/stcat_rng.h rebuilds the 124 masks, the oracle runs with them in fp32, and outputs, span and the 30 losses
+    reproduce the stored ones; the eval-mode fixture of the same clip is far away (the masks matter)."""
+    from tests import test_model_parity as P
+    g = _load(golden_dir, "model_C1_train.npz")
+    T, H, W, L = (int(v) for v in g["meta/config"])
+    assert (T, H, W, L) == (8, 224, 224, 10) and str(g["meta/source"]).startswith("oracle")
+    sites = [(int(o), int(n)) for o, n in g["dropout/sites"]]
+    assert len(sites) == 12 * 4 + 6 * 6 + 6 * 6 + 4
+    seed, base = int(g["dropout/seed"]), int(g["dropout/base"])
+    out, boxes, sted, losses, _ = P._run_oracle(T, H, L, True, torch.float32, None,
+                                                lambda: P._HipMasks(sites, seed, base), trainable_only=True)
+    for k in ("pred_boxes", "pred_sted", "pred_actioness", "weights"):
+        _close(out[k].detach().numpy(), g[f"out/{k}"], 2e-6, "train fixture " + k)
+    assert [sted] == g["post/sted"].tolist()
+    for k, v in zip(g["loss/keys"], g["loss/values"]):
+        assert abs(losses[str(k)] - float(v)) <= 2e-5 * max(1.0, abs(float(v))), (k, losses[str(k)], float(v))
+    ev = _load(golden_dir, "model_C1.npz")
+    assert np.abs(ev["out/pred_sted"] - g["out/pred_sted"]).max() > 1e-2
