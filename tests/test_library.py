@@ -82,3 +82,34 @@ def test_gpu_side_streams_run_beside_the_current_stream():
         assert both < 1.5 * one, (both, one, rep)
     assert min(run((main, side, wg)) for _ in range(3)) < 1.5 * one
     assert ops.WgradStream(torch.empty(1, device=dev)).side is wg
+
+
+@pytest.mark.gpu
+def test_gpu_stream_constructor_of_the_background_lane():
+    """round 6: stcat_stream_create / stcat_stream_destroy — a HIP stream of the device's least / greatest priority or one
+    restricted to n compute units (the lanes measured for the pipelined prefix, profiles/r06_prefix_pipeline.log); kernels
+    run on them, a torch ExternalStream wraps them, bad arguments are refused"""
+    from stcat_amd import ops
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L._lib = None
+    L._backend = "hip"
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    for prio, cus in ((1, 0), (-1, 0), (0, 0), (0, 128)):
+        out = ctypes.c_void_p()
+        assert lib.stcat_stream_create(prio, cus, ctypes.byref(out)) == 0, lib.stcat_last_error()
+        assert out.value
+        st = torch.cuda.ExternalStream(out.value, device=dev)
+        x = torch.zeros(1 << 16, device=dev)
+        st.wait_stream(torch.cuda.current_stream(dev))
+        assert lib.stcat_spin(100, st.cuda_stream) == 0
+        with torch.cuda.stream(st):
+            y = ops.ew(L.EW_ADD, x, torch.ones_like(x))
+        torch.cuda.current_stream(dev).wait_stream(st)
+        assert float(y.sum()) == float(1 << 16)
+        torch.cuda.synchronize(dev)
+        assert lib.stcat_stream_destroy(out) == 0
+    assert lib.stcat_stream_create(0, 0, None) != 0          # no place to return the handle
+    out = ctypes.c_void_p()
+    assert lib.stcat_stream_create(0, 5000, ctypes.byref(out)) != 0 and not out.value
